@@ -1,0 +1,400 @@
+"""TEST INFRASTRUCTURE ONLY -- the oracle for the GL-Fusion hot path.
+
+A plain PyTorch-CPU fp32 restatement of the reference's forward/backward hot path
+(SURVEY.md section 8a, rows a1-a10).  It is the checker for the HIP engine in
+gl-fusion_amd/; it is never the thing measured (except as bench.py's reported
+``cpu_baseline``) and never shipped on the product path.
+
+Pinning status
+--------------
+* a1, a2 (conv1 swap), a4, a5, a6, a7, a9, a10: PINNED by tests/golden/*.npz, which
+  were generated in the build container by importing the reference's own
+  ``models/ours.py`` (tests/golden/make_golden.py) and executing it on CPU.
+* a3 (ResNet-50 Bottleneck arithmetic): PARITY UNPINNED.  The reference takes it from
+  torchvision==0.9.1 (requirements.txt:25; call site models/segmentation.py:205-207),
+  which is neither vendored under /root/reference nor installed here.  ``ResNet50Trunk``
+  below restates the published v1.5 architecture; the only in-tree structural evidence
+  is models/resnet.py:43-79 (same block, no dilation) and the shape comments in
+  models/_utils.py:214-217.  The golden generator plugs this same class in as the
+  torchvision stand-in, so the fixtures pin the wiring around it, not its arithmetic.
+
+All file:line citations are relative to /root/reference/GLfusion/.
+"""
+from __future__ import annotations
+
+import copy
+from collections import OrderedDict
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# a3: ResNet-50 (torchvision 0.9.1 `resnet50(replace_stride_with_dilation=[F,T,T])`)
+# --------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    """1x1 -> BN -> ReLU -> 3x3(stride, dilation) -> BN -> ReLU -> 1x1 -> BN -> (+id) -> ReLU.
+
+    Structure pinned in-tree only by models/resnet.py:43-79; stride lives on the 3x3
+    (the "v1.5" variant torchvision ships)."""
+
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: nn.Module | None = None, dilation: int = 1) -> None:
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation,
+                               dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + skip)
+
+
+class ResNet50Trunk(nn.Module):
+    """Child order conv1,bn1,relu,maxpool,layer1..4,avgpool,fc matters: the reference's
+    IntermediateLayerGetter walks named_children() in order (models/segmentation.py:67-72)."""
+
+    def __init__(self, replace_stride_with_dilation: Sequence[bool] = (False, True, True),
+                 num_classes: int = 1000) -> None:
+        super().__init__()
+        self.inplanes = 64
+        self.dilation = 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._stage(64, 3, 1, False)
+        self.layer2 = self._stage(128, 4, 2, replace_stride_with_dilation[0])
+        self.layer3 = self._stage(256, 6, 2, replace_stride_with_dilation[1])
+        self.layer4 = self._stage(512, 3, 2, replace_stride_with_dilation[2])
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(2048, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _stage(self, planes: int, blocks: int, stride: int, dilate: bool) -> nn.Sequential:
+        prev_dilation = self.dilation
+        if dilate:                       # stride traded for dilation
+            self.dilation *= stride
+            stride = 1
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+        mods = [Bottleneck(self.inplanes, planes, stride, down, prev_dilation)]
+        self.inplanes = planes * 4
+        mods += [Bottleneck(self.inplanes, planes, dilation=self.dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+
+def resnet50(pretrained: bool = False, progress: bool = True, **kw) -> ResNet50Trunk:
+    """Drop-in for torchvision.models.resnet.resnet50; `pretrained` is ignored (no network)."""
+    return ResNet50Trunk(kw.get("replace_stride_with_dilation", (False, False, False)))
+
+
+# --------------------------------------------------------------------------------------
+# a4: DeepLabHead / ASPP (models/deeplabv3.py:102-166)
+# --------------------------------------------------------------------------------------
+class _ConvBNReLU(nn.Sequential):
+    def __init__(self, cin: int, cout: int, k: int, dilation: int = 1) -> None:
+        pad = 0 if k == 1 else dilation
+        super().__init__(nn.Conv2d(cin, cout, k, padding=pad, dilation=dilation, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class ASPPPooling(nn.Sequential):
+    """deeplabv3.py:123-135 -- global average -> 1x1 -> BN -> ReLU -> bilinear from 1x1
+    (a broadcast)."""
+
+    def __init__(self, cin: int, cout: int) -> None:
+        super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        hw = x.shape[-2:]
+        for m in self:
+            x = m(x)
+        return F.interpolate(x, size=hw, mode="bilinear", align_corners=False)
+
+
+class ASPP(nn.Module):
+    """deeplabv3.py:138-166."""
+
+    def __init__(self, in_channels: int, atrous_rates: Sequence[int], out_channels: int = 256) -> None:
+        super().__init__()
+        branches: List[nn.Module] = [_ConvBNReLU(in_channels, out_channels, 1)]
+        branches += [_ConvBNReLU(in_channels, out_channels, 3, r) for r in atrous_rates]
+        branches.append(ASPPPooling(in_channels, out_channels))
+        self.convs = nn.ModuleList(branches)
+        self.project = nn.Sequential(
+            nn.Conv2d(len(branches) * out_channels, out_channels, 1, bias=False),
+            nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.project(torch.cat([b(x) for b in self.convs], dim=1))
+
+
+class DeepLabHead(nn.Sequential):
+    """deeplabv3.py:102-110."""
+
+    def __init__(self, in_channels: int, num_classes: int) -> None:
+        super().__init__(ASPP(in_channels, [12, 24, 36]),
+                         nn.Conv2d(256, 256, 3, padding=1, bias=False),
+                         nn.BatchNorm2d(256), nn.ReLU(),
+                         nn.Conv2d(256, num_classes, 1))
+
+
+# --------------------------------------------------------------------------------------
+# a10: the template factory (models/segmentation.py:484-500, 197-244; _utils.py:180-193)
+# --------------------------------------------------------------------------------------
+class _Template(nn.Module):
+    """Stand-in for DeepLabV3_iekd: .backbone is a ModuleDict of the trunk children up to
+    layer4 (IntermediateLayerGetter, segmentation.py:55-72) and conv1 is swapped for a
+    1-channel 7x7 stride-1 pad-2 conv WITH bias (_utils.py:192)."""
+
+    def __init__(self, num_classes: int) -> None:
+        super().__init__()
+        trunk = ResNet50Trunk((False, True, True))
+        kept = OrderedDict()
+        for name, child in trunk.named_children():
+            kept[name] = child
+            if name == "layer4":
+                break
+        self.backbone = nn.ModuleDict(kept)
+        self.classifier = DeepLabHead(2048, num_classes)
+        self.backbone["conv1"] = nn.Conv2d(1, 64, kernel_size=7, stride=1, padding=2)
+
+
+def deeplabv3_resnet50_iekd(pretrained: bool = False, progress: bool = True,
+                            num_classes: int = 21, aux_loss=None, **kw) -> _Template:
+    return _Template(num_classes)
+
+
+# --------------------------------------------------------------------------------------
+# a6: TPAVIModule (models/ours.py:770-917), modes 'dot' and 'embedded' only
+# --------------------------------------------------------------------------------------
+class TPAVIModule(nn.Module):
+    def __init__(self, in_channels: int, inter_channels: int | None = None, mode: str = "dot",
+                 dimension: int = 3, bn_layer: bool = True) -> None:
+        super().__init__()
+        if mode not in ("dot", "embedded"):
+            raise ValueError("oracle restates modes 'dot' and 'embedded' only")
+        if dimension != 3 or not bn_layer:
+            raise ValueError("oracle restates dimension=3, bn_layer=True only")
+        self.mode, self.dimension = mode, dimension
+        self.in_channels = in_channels
+        self.inter_channels = inter_channels or max(in_channels // 2, 1)
+        self.align_channel = nn.Linear(128, in_channels)       # ours.py:796 (dead for this model)
+        self.norm_layer = nn.LayerNorm(in_channels)            # ours.py:797
+        ci = self.inter_channels
+        self.g = nn.Conv3d(in_channels, ci, 1)                 # ours.py:816
+        self.W_z = nn.Sequential(nn.Conv3d(ci, in_channels, 1), nn.BatchNorm3d(in_channels))
+        nn.init.zeros_(self.W_z[1].weight)                     # ours.py:826-827
+        nn.init.zeros_(self.W_z[1].bias)
+        self.theta = nn.Conv3d(in_channels, ci, 1)             # ours.py:836
+        self.phi = nn.Conv3d(in_channels, ci, 1)               # ours.py:837
+
+    def forward(self, x: torch.Tensor, audio=None):
+        if audio is not None:
+            raise ValueError("audio branch (ours.py:855-861) is not on the path")
+        n = x.size(0)
+        ci = self.inter_channels
+        g_x = self.g(x).view(n, ci, -1).transpose(1, 2)            # [n, L, ci]   ours.py:866-869
+        th = self.theta(x).view(n, ci, -1).transpose(1, 2)         # [n, L, ci]   ours.py:878,880
+        ph = self.phi(x).view(n, ci, -1)                           # [n, ci, L]   ours.py:879
+        f = torch.matmul(th, ph)                                   # [n, L, L]    ours.py:881
+        if self.mode == "embedded":
+            f = F.softmax(f, dim=-1)                               # ours.py:896-897
+        else:
+            f = f / f.size(-1)                                     # ours.py:898-900
+        y = torch.matmul(f, g_x)                                   # [n, L, ci]   ours.py:902
+        y = y.transpose(1, 2).contiguous().view(n, ci, *x.shape[2:])
+        z = self.W_z(y) + x                                        # ours.py:908-910
+        z = self.norm_layer(z.permute(0, 2, 3, 4, 1)).permute(0, 4, 1, 2, 3)   # ours.py:913-915
+        return z, 0
+
+
+# --------------------------------------------------------------------------------------
+# a1: Global_and_Local (models/ours.py:1708-1843)
+# --------------------------------------------------------------------------------------
+class Global_and_Local(nn.Module):
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"),
+                 center_aware_weight: float = 20) -> None:
+        super().__init__()
+        self.view_num = list(view_num)
+        self.test_view = list(test_view)
+        self.center_aware_weight = center_aware_weight
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)   # ours.py:1716
+        self.init_block = nn.ModuleDict()
+        self.layer1, self.layer2 = nn.ModuleDict(), nn.ModuleDict()
+        self.layer3, self.layer4 = nn.ModuleDict(), nn.ModuleDict()
+        self.classifier, self.centerness = nn.ModuleDict(), nn.ModuleDict()
+        bb = self.network.backbone
+        for v in self.view_num:                                                    # ours.py:1724-1744
+            self.init_block[v] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            self.layer1[v] = copy.deepcopy(bb["layer1"])
+            self.layer2[v] = copy.deepcopy(bb["layer2"])
+            self.layer3[v] = copy.deepcopy(bb["layer3"])
+            self.layer4[v] = copy.deepcopy(bb["layer4"])
+            self.classifier[v] = copy.deepcopy(self.network.classifier)
+            self.classifier[v][-1] = nn.Conv2d(256, 5, kernel_size=1)
+            self.centerness[v] = copy.deepcopy(self.network.classifier)
+            self.centerness[v][-1] = nn.Conv2d(256, 1, kernel_size=1)
+        self.global_attn = TPAVIModule(2048, mode="dot")                           # ours.py:1746
+        self.local_attn = TPAVIModule(2048, mode="dot")                            # ours.py:1747
+
+    def encode(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        f4 = {}
+        for v in self.view_num:                                                    # ours.py:1795-1800
+            f = self.init_block[v](x[v])
+            f = self.layer1[v](f)
+            f = self.layer2[v](f)
+            f = self.layer3[v](f)
+            f4[v] = self.layer4[v](f)
+        return f4
+
+    def backbone(self, x):                                                         # ours.py:1749-1773
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self.encode(x)
+        mask = {v: F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
+                for v in self.view_num}
+        return mask, f4
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self.encode(x)
+        f4_local = {}
+        for v in self.view_num:
+            # ours.py:1802-1807: AdaptiveMaxPool3d((1,h,w)) on a 4-D tensor == max over the class channels
+            m = torch.sigmoid(self.classifier[v](f4[v])).amax(dim=1, keepdim=True)
+            c = torch.sigmoid(self.centerness[v](f4[v]))                           # ours.py:1809-1811
+            a = torch.sigmoid(self.center_aware_weight * m * c)                    # ours.py:1814-1815
+            f4_local[v] = f4[v] * a                                                # ours.py:1816
+        g_out, _ = self.global_attn(torch.stack([f4[v] for v in self.view_num], dim=2))        # ours.py:1819-1821
+        l_out, _ = self.local_attn(torch.stack([f4_local[v] for v in self.view_num], dim=2))   # ours.py:1826-1828
+        f4_g = {v: g_out[:, :, i] for i, v in enumerate(self.view_num)}
+        f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
+        mask, mask_bb = {}, {}
+        for v in self.view_num:                                                    # ours.py:1833-1841
+            fused = f4_g[v] + f4_l[v]
+            mask[v] = F.interpolate(self.classifier[v](fused), size=hw, mode="bilinear", align_corners=False)
+            mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
+        return mask, mask_bb, f4_g, f4_l
+
+
+# --------------------------------------------------------------------------------------
+# a8 / a9: the caller's step and metrics (main.py:87,202-243 and main.py:800-815)
+# --------------------------------------------------------------------------------------
+def overlap_metrics(gt: torch.Tensor, pred: torch.Tensor, eps: float = 1e-5):
+    """main.py:800-815. Returns (pixel_acc, dice, precision, specificity, recall)."""
+    o = pred.reshape(-1).float()
+    t = gt.reshape(-1).float()
+    tp = torch.sum(o * t)
+    fp = torch.sum(o * (1 - t))
+    fn = torch.sum((1 - o) * t)
+    tn = torch.sum((1 - o) * (1 - t))
+    return ((tp + tn) / (tp + tn + fp + fn + eps), 2 * tp / (2 * tp + fp + fn + eps),
+            tp / (tp + fp + eps), tn / (tn + fp + eps), tp / (tp + fn + eps))
+
+
+def binarize(logits: torch.Tensor) -> torch.Tensor:
+    """main.py:250,385: torch.where(sigmoid(x) > 0.5, 1, 0)."""
+    return torch.where(torch.sigmoid(logits) > 0.5, 1, 0)
+
+
+def seg_loss(model: nn.Module, imgs: Dict[str, torch.Tensor], masks: Dict[str, torch.Tensor],
+             views: Sequence[str] | None = None) -> torch.Tensor:
+    """main.py:207-211: sum over views of BCEWithLogitsLoss(reduction='sum') on output 0."""
+    pred = model(imgs)[0]
+    bce = nn.BCEWithLogitsLoss(reduction="sum")
+    return sum(bce(pred[v], masks[v]) for v in (views or list(pred.keys())))
+
+
+def train_step(model: nn.Module, imgs, masks) -> float:
+    """forward -> sum_v BCE-sum -> backward (no optimizer step), as the metric defines."""
+    for p in model.parameters():
+        p.grad = None
+    loss = seg_loss(model, imgs, masks)
+    loss.backward()
+    return float(loss.detach())
+
+
+# --------------------------------------------------------------------------------------
+# Deterministic, RNG-free fills shared by the golden generator, the tests and smoke()
+# --------------------------------------------------------------------------------------
+def _hash_unit(n: int, salt: int) -> np.ndarray:
+    """n values in [0,1) from an exact 64-bit integer hash of (index, salt); bit-identical
+    on every platform (no libm)."""
+    x = np.arange(n, dtype=np.uint64) + np.uint64((salt * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def closed_form_tensor(shape, salt: int, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = _hash_unit(n, salt)
+    return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32)).reshape(tuple(shape))
+
+
+@torch.no_grad()
+def closed_form_fill(module: nn.Module, salt: int = 0) -> None:
+    """Fill state_dict() in key order with a closed-form rule so that fixtures need not
+    store weights.  conv/linear weights: centred uniform with He-like scale; 1-D `weight`
+    (norm gammas, incl. the zero-initialised W_z BN gamma so attention is live): 1 +- 0.1;
+    biases / betas / running_mean: +-0.05; running_var: 1..1.25."""
+    for k, (name, t) in enumerate(module.state_dict().items()):
+        s = salt * 100003 + k + 1
+        if name.endswith("num_batches_tracked"):
+            t.zero_()
+        elif name.endswith("running_var"):
+            t.copy_(closed_form_tensor(t.shape, s, 1.0, 1.25))
+        elif name.endswith("running_mean"):
+            t.copy_(closed_form_tensor(t.shape, s, -0.05, 0.05))
+        elif t.dim() >= 2:
+            fan_in = int(np.prod(t.shape[1:]))
+            b = float(np.sqrt(6.0 / fan_in))          # uniform(-b, b): var = 2/fan_in
+            t.copy_(closed_form_tensor(t.shape, s, -b, b))
+        elif name.endswith("weight"):
+            t.copy_(closed_form_tensor(t.shape, s, 0.9, 1.1))
+        else:
+            t.copy_(closed_form_tensor(t.shape, s, -0.05, 0.05))
+
+
+def closed_form_images(views: Sequence[str], n: int, h: int = 112, w: int = 112, salt: int = 7):
+    return {v: closed_form_tensor((n, 1, h, w), salt * 1000 + i) for i, v in enumerate(views)}
+
+
+def closed_form_targets(views: Sequence[str], n: int, c: int = 5, h: int = 112, w: int = 112,
+                        salt: int = 11, p: float = 0.3):
+    return {v: (closed_form_tensor((n, c, h, w), salt * 1000 + i) < p).float()
+            for i, v in enumerate(views)}
+
+
+def set_dropout(module: nn.Module, p: float) -> None:
+    for m in module.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = p

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE's own models/ours.py on CPU.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are
+plain data (inputs are closed-form, outputs are arrays) and travel with the repo.
+
+Recipe: the reference imports three packages that are absent
+here and unused by the model code -- monai.data.DataLoader, tensorboardX.SummaryWriter --
+plus torchvision.models.resnet (absent; supplies ResNet-50).  We register in-memory
+stand-ins before importing: the first two are empty placeholders, the third exposes the
+oracle's own ResNet-50 restatement (oracle/glfusion_ref.py::resnet50).  Everything else on
+the path (conv1 swap, DeepLabHead/ASPP, TPAVIModule, Global_and_Local wiring) is the
+reference's code, executed verbatim.
+
+Weights are never stored: both sides fill state_dict() with oracle.closed_form_fill.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/GLfusion"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from oracle import glfusion_ref as orc  # noqa: E402
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    monai = stub("monai")
+    monai.data = stub("monai.data", DataLoader=object)
+    stub("tensorboardX", SummaryWriter=object)
+    tv = stub("torchvision")
+    tv.models = stub("torchvision.models")
+    tv.models.resnet = stub("torchvision.models.resnet", resnet50=orc.resnet50)
+    sys.path.insert(0, REF)
+    import models.ours as ours          # noqa: E402
+    import models.deeplabv3 as dl       # noqa: E402
+    return ours, dl
+
+
+def sample_idx(n: int, k: int = 257) -> np.ndarray:
+    return np.unique(np.linspace(0, n - 1, num=min(k, n)).astype(np.int64))
+
+
+def t2n(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().numpy()
+
+
+def grads_summary(model: torch.nn.Module):
+    """per-parameter L2 norm and a strided sample of each gradient (None -> norm -1)."""
+    names, norms, samples = [], [], {}
+    for name, p in model.named_parameters():
+        names.append(name)
+        if p.grad is None:
+            norms.append(-1.0)
+            continue
+        g = p.grad.detach().double().reshape(-1)
+        norms.append(float(g.norm()))
+        samples[name] = t2n(p.grad.reshape(-1)[torch.from_numpy(sample_idx(g.numel(), 33))])
+    return names, np.array(norms), samples
+
+
+def main() -> None:
+    torch.manual_seed(0)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ours, dl = import_reference()
+    out = {}
+
+    # ------------------------------------------------------------------ unit: TPAVIModule
+    for mode in ("dot", "embedded"):
+        m = ours.TPAVIModule(in_channels=64, mode=mode)
+        orc.closed_form_fill(m, salt=3)
+        m.train()
+        x = orc.closed_form_tensor((2, 64, 3, 6, 5), 101, -1.0, 1.0).requires_grad_(True)
+        z, _ = m(x)
+        w = orc.closed_form_tensor(tuple(z.shape), 102, -1.0, 1.0)
+        (z * w).sum().backward()
+        names, norms, samples = grads_summary(m)
+        d = {"z": t2n(z), "dx": t2n(x.grad), "grad_names": np.array(names), "grad_norms": norms,
+             "rm": t2n(m.W_z[1].running_mean), "rv": t2n(m.W_z[1].running_var)}
+        d.update({"g:" + k: v for k, v in samples.items()})
+        m.eval()
+        with torch.no_grad():
+            d["z_eval"] = t2n(m(x.detach())[0])
+        np.savez_compressed(os.path.join(HERE, f"tpavi_{mode}.npz"), **d)
+        print("tpavi", mode, "|z|max", float(z.abs().max()))
+
+    # ------------------------------------------------------------------ unit: DeepLabHead
+    head = dl.DeepLabHead(64, 5)
+    orc.closed_form_fill(head, salt=5)
+    orc.set_dropout(head, 0.0)
+    x = orc.closed_form_tensor((2, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)
+    head.train()
+    y = head(x)
+    w = orc.closed_form_tensor(tuple(y.shape), 202, -1.0, 1.0)
+    (y * w).sum().backward()
+    names, norms, samples = grads_summary(head)
+    d = {"y_train": t2n(y), "dx": t2n(x.grad), "grad_names": np.array(names), "grad_norms": norms}
+    d.update({"g:" + k: v for k, v in samples.items()})
+    d.update({"bn:" + k: t2n(v) for k, v in head.state_dict().items() if "running" in k})
+    head2 = dl.DeepLabHead(64, 5)
+    orc.closed_form_fill(head2, salt=5)
+    head2.eval()
+    with torch.no_grad():
+        d["y_eval"] = t2n(head2(x.detach()))
+    np.savez_compressed(os.path.join(HERE, "deeplab_head.npz"), **d)
+    print("head |y|max", float(y.abs().max()))
+
+    # ------------------------------------------------------------------ e2e eval, config-2 views, N=2
+    for tag, views, n in (("c2", ["1", "3", "4"], 2), ("c1", ["1"], 8)):
+        model = ours.Global_and_Local(view_num=views)
+        keys = list(model.state_dict().keys())
+        orc.closed_form_fill(model, salt=1)
+        model.eval()
+        imgs = orc.closed_form_images(views, n)
+        tgts = orc.closed_form_targets(views, n)
+        with torch.no_grad():
+            mask, mask_bb, fg, fl = model(imgs)
+        d = {"n_keys": np.array(len(keys)), "keys_head": np.array(keys[:8] + keys[-8:])}
+        for v in views:
+            d[f"mask:{v}"] = t2n(mask[v])
+            d[f"mask_bb:{v}"] = t2n(mask_bb[v])
+            pred = torch.where(torch.sigmoid(mask[v]) > 0.5, 1, 0)
+            # reference metric code path: main.py:800-815 restated in the oracle; the dice of the
+            # reference logits vs the closed-form targets
+            d[f"dice:{v}"] = np.array([float(x) for x in orc.overlap_metrics(tgts[v], pred)])
+            d[f"pos_frac:{v}"] = np.array(float(pred.float().mean()))
+            d[f"near_zero:{v}"] = np.array(int((mask[v].abs() < 1e-4).sum()))
+            for nm, f in (("fg", fg[v]), ("fl", fl[v])):
+                flat = f.reshape(-1)
+                idx = sample_idx(flat.numel(), 4099)
+                d[f"{nm}_idx:{v}"] = idx
+                d[f"{nm}_val:{v}"] = t2n(flat[torch.from_numpy(idx)])
+                d[f"{nm}_sum:{v}"] = np.array([float(f.double().sum()), float(f.double().abs().sum())])
+            print(tag, v, "pos_frac", float(d[f"pos_frac:{v}"]), "dice", d[f"dice:{v}"][1],
+                  "near0", int(d[f"near_zero:{v}"]), "|mask|max", float(mask[v].abs().max()))
+        np.savez_compressed(os.path.join(HERE, f"e2e_eval_{tag}.npz"), **d)
+        if tag == "c2":
+            with open(os.path.join(HERE, "state_dict_keys.txt"), "w") as fh:
+                for k in keys:
+                    fh.write(f"{k} {tuple(model.state_dict()[k].shape)}\n")
+
+    # ------------------------------------------------------------------ train-mode step, dropout p = 0
+    views, n = ["1", "3", "4"], 2
+    model = ours.Global_and_Local(view_num=views)
+    orc.closed_form_fill(model, salt=1)
+    orc.set_dropout(model, 0.0)
+    model.train()
+    imgs = orc.closed_form_images(views, n)
+    tgts = orc.closed_form_targets(views, n)
+    pred, _, _, _ = model(imgs)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="sum")          # main.py:87
+    loss = sum(bce(pred[v], tgts[v]) for v in views)           # main.py:209-211
+    loss.backward()                                            # main.py:241
+    names, norms, samples = grads_summary(model)
+    d = {"loss": np.array(float(loss)), "grad_names": np.array(names), "grad_norms": norms}
+    d.update({"g:" + k: v for k, v in samples.items()})
+    for v in views:
+        d[f"mask:{v}"] = t2n(pred[v])
+    sd = model.state_dict()
+    for k in sd:
+        if ("running_mean" in k or "running_var" in k or "num_batches" in k) and not k.startswith("network."):
+            # store a strided sample of every running stat (3 momentum updates for classifier BNs)
+            flat = sd[k].reshape(-1).float()
+            d["bn:" + k] = t2n(flat[torch.from_numpy(sample_idx(flat.numel(), 9))])
+    np.savez_compressed(os.path.join(HERE, "e2e_train_step.npz"), **d)
+    print("train loss", float(loss))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""CPU: the oracle (oracle/glfusion_ref.py) against the golden vectors produced by executing
+the reference's own models/ours.py (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import glfusion_ref as orc
+
+TOL = 1e-4   # north_star: masks / Dice within 1e-4 fp32
+
+
+def close(a, b, tol=TOL):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return bool(((a - b).abs() <= tol + tol * b.abs()).all())
+
+
+@pytest.mark.parametrize("mode", ["dot", "embedded"])
+def test_tpavi_unit(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, f"tpavi_{mode}.npz"))
+    m = orc.TPAVIModule(64, mode=mode)
+    orc.closed_form_fill(m, salt=3)
+    m.train()
+    x = orc.closed_form_tensor((2, 64, 3, 6, 5), 101, -1.0, 1.0).requires_grad_(True)
+    z, _ = m(x)
+    w = orc.closed_form_tensor(tuple(z.shape), 102, -1.0, 1.0)
+    (z * w).sum().backward()
+    assert close(z.detach(), g["z"], 1e-5)
+    assert close(x.grad, g["dx"], 1e-5)
+    assert close(m.W_z[1].running_mean, g["rm"], 1e-6) and close(m.W_z[1].running_var, g["rv"], 1e-6)
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            assert norms[name] == -1.0
+        else:
+            assert abs(float(p.grad.double().norm()) - norms[name]) <= 1e-5 * max(1.0, norms[name])
+    m.eval()
+    with torch.no_grad():
+        assert close(m(x.detach())[0], g["z_eval"], 1e-5)
+
+
+def test_deeplab_head_unit(golden_dir):
+    g = np.load(os.path.join(golden_dir, "deeplab_head.npz"))
+    head = orc.DeepLabHead(64, 5)
+    orc.closed_form_fill(head, salt=5)
+    orc.set_dropout(head, 0.0)
+    x = orc.closed_form_tensor((2, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)
+    head.train()
+    y = head(x)
+    w = orc.closed_form_tensor(tuple(y.shape), 202, -1.0, 1.0)
+    (y * w).sum().backward()
+    assert close(y.detach(), g["y_train"], 1e-5)
+    assert close(x.grad, g["dx"], 1e-4)
+    for k, v in head.state_dict().items():
+        if "running" in k:
+            assert close(v, g["bn:" + k], 1e-6)
+    head2 = orc.DeepLabHead(64, 5)          # fresh running stats, as the generator does
+    orc.closed_form_fill(head2, salt=5)
+    head2.eval()
+    with torch.no_grad():
+        assert close(head2(x.detach()), g["y_eval"], 1e-5)
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    want = [ln.split(" ", 1) for ln in open(os.path.join(golden_dir, "state_dict_keys.txt")).read().splitlines()]
+    m = orc.Global_and_Local(["1", "3", "4"])
+    got = [(k, str(tuple(v.shape))) for k, v in m.state_dict().items()]
+    assert len(got) == 1618
+    assert [k for k, _ in got] == [k for k, _ in want]
+    assert [s for _, s in got] == [s for _, s in want]
+    assert sum(p.numel() for p in m.parameters()) == 224227623
+
+
+@pytest.mark.parametrize("tag,views,n", [("c2", ["1", "3", "4"], 2), ("c1", ["1"], 8)])
+def test_e2e_eval(golden_dir, tag, views, n):
+    g = np.load(os.path.join(golden_dir, f"e2e_eval_{tag}.npz"))
+    model = orc.Global_and_Local(views)
+    orc.closed_form_fill(model, salt=1)
+    model.eval()
+    imgs = orc.closed_form_images(views, n)
+    tgts = orc.closed_form_targets(views, n)
+    with torch.no_grad():
+        mask, mask_bb, fg, fl = model(imgs)
+    for v in views:
+        assert close(mask[v], g[f"mask:{v}"])
+        assert close(mask_bb[v], g[f"mask_bb:{v}"])
+        ref = torch.from_numpy(g[f"mask:{v}"])
+        bits_differ = orc.binarize(mask[v]) != orc.binarize(ref)
+        assert bool((ref.abs()[bits_differ] < TOL).all())      # bits may differ only where |logit| < tol
+        dice = [float(x) for x in orc.overlap_metrics(tgts[v], orc.binarize(mask[v]))]
+        assert np.allclose(dice, g[f"dice:{v}"], atol=TOL, rtol=0)
+        for nm, f in (("fg", fg[v]), ("fl", fl[v])):
+            idx = torch.from_numpy(g[f"{nm}_idx:{v}"])
+            assert close(f.reshape(-1)[idx], g[f"{nm}_val:{v}"])
+
+
+def test_e2e_train_step(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_train_step.npz"))
+    views, n = ["1", "3", "4"], 2
+    model = orc.Global_and_Local(views)
+    orc.closed_form_fill(model, salt=1)
+    orc.set_dropout(model, 0.0)
+    model.train()
+    loss = orc.train_step(model, orc.closed_form_images(views, n), orc.closed_form_targets(views, n))
+    assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            assert norms[name] == -1.0, name
+        elif name.endswith(".0.bias") and (name.startswith("init_block") or ".W_z.0." in name):
+            # a conv bias feeding a train-mode BatchNorm has an exactly-zero true gradient: both sides
+            # hold only rounding noise, bounded relative to the companion weight gradient
+            gw = norms[name[:-4] + "weight"]
+            assert float(p.grad.double().norm()) <= 1e-4 * gw and norms[name] <= 1e-4 * gw, name
+        else:
+            gn = float(p.grad.double().norm())
+            assert abs(gn - norms[name]) <= 2e-3 * max(norms[name], 1e-3), (name, gn, norms[name])
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("bn:"):
+            flat = sd[k[3:]].reshape(-1).float()
+            idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(9, flat.numel())).astype(np.int64))
+            assert close(flat[torch.from_numpy(idx)], g[k], 1e-5), k
