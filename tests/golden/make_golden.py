@@ -167,6 +167,20 @@ def main() -> None:
     loss.backward()                                            # main.py:241
     names, norms, samples = grads_summary(model)
     d = {"loss": np.array(float(loss)), "grad_names": np.array(names), "grad_norms": norms}
+    # the same step executed by the reference in float64: lets the tests size each gradient's
+    # tolerance by the reference's own fp32 rounding noise (BN over N=2 frames is ill-conditioned)
+    m64 = ours.Global_and_Local(view_num=views)
+    orc.closed_form_fill(m64, salt=1)
+    orc.set_dropout(m64, 0.0)
+    m64.double().train()
+    p64, _, _, _ = m64({v: imgs[v].double() for v in views})
+    l64 = sum(bce(p64[v], tgts[v].double()) for v in views)
+    l64.backward()
+    _, norms64, samples64 = grads_summary(m64)
+    d["loss64"] = np.array(float(l64))
+    d["grad_norms64"] = norms64
+    d.update({"g64:" + k: v for k, v in samples64.items()})
+    del m64, p64, l64
     d.update({"g:" + k: v for k, v in samples.items()})
     for v in views:
         d[f"mask:{v}"] = t2n(pred[v])

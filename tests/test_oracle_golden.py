@@ -106,6 +106,7 @@ def test_e2e_train_step(golden_dir):
     loss = orc.train_step(model, orc.closed_form_images(views, n), orc.closed_form_targets(views, n))
     assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    norms64 = dict(zip(g["grad_names"].tolist(), g["grad_norms64"].tolist()))
     for name, p in model.named_parameters():
         if p.grad is None:
             assert norms[name] == -1.0, name
@@ -115,8 +116,10 @@ def test_e2e_train_step(golden_dir):
             gw = norms[name[:-4] + "weight"]
             assert float(p.grad.double().norm()) <= 1e-4 * gw and norms[name] <= 1e-4 * gw, name
         else:
+            # tolerance = the larger of 2e-3 relative and 10x the reference's own fp32-vs-fp64 noise
             gn = float(p.grad.double().norm())
-            assert abs(gn - norms[name]) <= 2e-3 * max(norms[name], 1e-3), (name, gn, norms[name])
+            tol = max(2e-3 * norms64[name], 10 * abs(norms[name] - norms64[name]), 1e-6)
+            assert abs(gn - norms64[name]) <= tol, (name, gn, norms[name], norms64[name])
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("bn:"):
