@@ -1,0 +1,102 @@
+"""ctypes binding of libglfusion_hip.so (the C ABI declared in include/glfusion.h).
+
+The prototypes are generated from the header itself, so the Python side cannot drift from
+the ABI.  There is NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the product path never routes around the HIP engine).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Dict, List, Tuple
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(ROOT, "include", "glfusion.h")
+LIB_PATH = os.path.join(_PKG, "lib", "libglfusion_hip.so")
+
+
+class GemmParams(C.Structure):
+    """Mirror of glf_gemm_params (include/glfusion.h)."""
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("taps", C.c_int32), ("tap_mask", C.c_uint32),
+        ("tap_stride_b", C.c_int64),
+        ("gather", C.c_int32),
+        ("n_img", C.c_int32), ("hs", C.c_int32), ("ws", C.c_int32), ("hd", C.c_int32), ("wd", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("batch", C.c_int32),
+        ("batch_stride_a", C.c_int64), ("batch_stride_b", C.c_int64), ("batch_stride_c", C.c_int64),
+        ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32),
+    ]
+
+
+_SCALARS = {
+    "int": C.c_int, "float": C.c_float, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+    "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None,
+}
+
+
+def _ctype(decl: str):
+    decl = re.sub(r"/\*.*?\*/", "", decl).strip()
+    if decl == "void":
+        return None
+    if "glf_gemm_params" in decl:
+        return C.POINTER(GemmParams)
+    if "*" in decl:
+        return C.c_void_p
+    t = decl.replace("const", "").split()
+    base = t[0]
+    if base not in _SCALARS:
+        raise ValueError(f"unmapped C type in {decl!r}")
+    return _SCALARS[base]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """{symbol: (restype, [argtypes])} for every function the header declares."""
+    text = open(path).read()
+    text_nc = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?m)^(const char\*|int|size_t)\s+(glf_\w+)\s*\(([^;{]*?)\)\s*;", text_nc, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = C.c_char_p if "char" in ret else (C.c_size_t if ret == "size_t" else C.c_int)
+        argtypes = [a for a in (_ctype(x) for x in args.split(",")) if a is not None] if args.strip() else []
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self) -> None:
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"GL-Fusion HIP engine not built: {LIB_PATH} is missing. Build it with "
+                f"`make -C {os.path.join(_PKG, 'csrc')}` (or __graft_entry__.build()). There is no CPU fallback.")
+        dll = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in self.protos.items():
+            fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self._dll = dll
+        return dll
+
+    def __getattr__(self, name: str):
+        if name.startswith("glf_"):
+            return getattr(self.load(), name)
+        raise AttributeError(name)
+
+
+lib = _Lib()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.glf_last_error()
+        raise RuntimeError(f"glfusion HIP call failed ({what}, status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,436 @@
+// Normalisation kernels of the GL-Fusion path (HBM-bound; channels-last [rows][C], C % 4 == 0).
+//   * column reductions (BatchNorm statistics, BatchNorm / LayerNorm / bias gradients) share one
+//     two-stage scheme: stage 1 streams a slice of rows per workgroup with 16-byte loads and
+//     accumulates in f64 (sum / sum-of-squares cancellation-free), stage 2 folds the per-slice
+//     partials per channel.  No atomics => bitwise reproducible.
+//   * BatchNorm apply (+residual, +ReLU) and the backward apply are single streaming passes.
+//   * the TPAVI tail z = LayerNorm_C(BN(W_z y) + x) runs one wavefront per row with shuffle
+//     reductions only (no LDS, no barrier).
+#include "glf_common.h"
+
+namespace {
+
+constexpr int RT = 256;               // threads of a reduction workgroup
+constexpr int MAX_SLICES = 1024;
+
+__host__ __device__ inline int n_slices(int rows) {
+    int s = (rows + 31) / 32;
+    return s < 1 ? 1 : (s > MAX_SLICES ? MAX_SLICES : s);
+}
+
+struct Coef { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+
+// ---- functors: two values per element --------------------------------------------------
+struct OpStats {          // (x, x^2)
+    const float* x; int ldx;
+    __device__ void operator()(int r, int c, float4& a, float4& b) const {
+        a = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
+        b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+    }
+};
+struct OpColsum {         // (dy, 0)
+    const float* dy; int ld;
+    __device__ void operator()(int r, int c, float4& a, float4& b) const {
+        a = *reinterpret_cast<const float4*>(dy + (long long)r * ld + c);
+        b = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+struct OpBnBwd {          // (dy', dy' * xhat), dy' = dy * (y > 0) when relu
+    const float* dy; int lddy; const float* x; int ldx; const float* y; int ldy;
+    const float* mean; const float* invstd; int relu;
+    __device__ void operator()(int r, int c, float4& a, float4& b) const {
+        a = *reinterpret_cast<const float4*>(dy + (long long)r * lddy + c);
+        if (relu) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + (long long)r * ldy + c);
+            a.x = yy.x > 0.f ? a.x : 0.f; a.y = yy.y > 0.f ? a.y : 0.f;
+            a.z = yy.z > 0.f ? a.z : 0.f; a.w = yy.w > 0.f ? a.w : 0.f;
+        }
+        const float4 xx = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        b = make_float4(a.x * (xx.x - mu.x) * is.x, a.y * (xx.y - mu.y) * is.y,
+                        a.z * (xx.z - mu.z) * is.z, a.w * (xx.w - mu.w) * is.w);
+    }
+};
+struct OpLnParam {        // (dz * uhat, dz) with u = BN(w) + x and per-row LayerNorm statistics
+    const float* dz; const float* w; const float* x; Coef bn; const float* row_mean; const float* row_rstd; int c_total;
+    __device__ void operator()(int r, int c, float4& a, float4& b) const {
+        const long long o = (long long)r * c_total + c;
+        b = *reinterpret_cast<const float4*>(dz + o);
+        const float4 ww = *reinterpret_cast<const float4*>(w + o);
+        const float4 xx = *reinterpret_cast<const float4*>(x + o);
+        const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(bn.gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(bn.beta + c);
+        const float m = row_mean[r], rs = row_rstd[r];
+        const float u0 = (ww.x - mu.x) * is.x * ga.x + be.x + xx.x;
+        const float u1 = (ww.y - mu.y) * is.y * ga.y + be.y + xx.y;
+        const float u2 = (ww.z - mu.z) * is.z * ga.z + be.z + xx.z;
+        const float u3 = (ww.w - mu.w) * is.w * ga.w + be.w + xx.w;
+        a = make_float4(b.x * (u0 - m) * rs, b.y * (u1 - m) * rs, b.z * (u2 - m) * rs, b.w * (u3 - m) * rs);
+    }
+};
+
+// stage 1: partial[0][slice][c], partial[1][slice][c]
+template <class Op>
+__global__ __launch_bounds__(RT) void colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ partial) {
+    __shared__ double sh_a[RT * 4];
+    __shared__ double sh_b[RT * 4];
+    const int tid = threadIdx.x;
+    const int c4 = c >> 2;
+    const int tpr = c4 < RT ? c4 : RT;            // threads per row
+    const int rpp = RT / tpr;                     // rows per pass
+    const int ct = tid % tpr, rl = tid / tpr;
+    const int slice = blockIdx.x;
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = slice * per, r1 = min(rows, r0 + per);
+    for (int cb = 0; cb < c4; cb += tpr) {
+        const int cc = cb + ct;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (cc < c4 && rl < rpp) {
+            for (int r = r0 + rl; r < r1; r += rpp) {
+                float4 a, b;
+                op(r, cc * 4, a, b);
+                a0 += a.x; a1 += a.y; a2 += a.z; a3 += a.w;
+                b0 += b.x; b1 += b.y; b2 += b.z; b3 += b.w;
+            }
+        }
+        sh_a[tid * 4 + 0] = a0; sh_a[tid * 4 + 1] = a1; sh_a[tid * 4 + 2] = a2; sh_a[tid * 4 + 3] = a3;
+        sh_b[tid * 4 + 0] = b0; sh_b[tid * 4 + 1] = b1; sh_b[tid * 4 + 2] = b2; sh_b[tid * 4 + 3] = b3;
+        __syncthreads();
+        if (rl == 0 && cc < c4) {
+            for (int q = 1; q < rpp; ++q) {
+                const int o = (q * tpr + ct) * 4;
+                a0 += sh_a[o]; a1 += sh_a[o + 1]; a2 += sh_a[o + 2]; a3 += sh_a[o + 3];
+                b0 += sh_b[o]; b1 += sh_b[o + 1]; b2 += sh_b[o + 2]; b3 += sh_b[o + 3];
+            }
+            double* pa = partial + (long long)slice * c + cc * 4;
+            double* pb = partial + (long long)(slices + slice) * c + cc * 4;
+            pa[0] = a0; pa[1] = a1; pa[2] = a2; pa[3] = a3;
+            pb[0] = b0; pb[1] = b1; pb[2] = b2; pb[3] = b3;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2 variants ------------------------------------------------------------------------
+__global__ void bn_stats_finalize(const double* __restrict__ partial, int slices, int c, int rows, float eps,
+                                  float momentum, float* mean, float* invstd, float* rmean, float* rvar, long long* nbt) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    if (ch == 0 && nbt) *nbt += 1;
+    double s = 0, q = 0;
+    for (int i = 0; i < slices; ++i) { s += partial[(long long)i * c + ch]; q += partial[(long long)(slices + i) * c + ch]; }
+    const double m = s / rows;
+    double var = q / rows - m * m;
+    if (var < 0) var = 0;
+    mean[ch] = (float)m;
+    invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+        rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)m;
+        rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+    }
+}
+
+// out_a[ch] = sum of first partial, out_b[ch] = sum of second (either may be NULL)
+__global__ void sum_finalize(const double* __restrict__ partial, int slices, int c, float* out_a, float* out_b) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0, q = 0;
+    for (int i = 0; i < slices; ++i) { s += partial[(long long)i * c + ch]; q += partial[(long long)(slices + i) * c + ch]; }
+    if (out_a) out_a[ch] = (float)s;
+    if (out_b) out_b[ch] = (float)q;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, float eps, float* mean, float* invstd, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    mean[ch] = rm[ch];
+    invstd[ch] = 1.0f / sqrtf(rv[ch] + eps);
+}
+
+// ---- streaming applies ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res, int ldr,
+                                                       float* __restrict__ y, int ldy, Coef k, long long total4, int c4, int relu) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        const float4 xx = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 mu = *reinterpret_cast<const float4*>(k.mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(k.beta + c);
+        float4 o = make_float4((xx.x - mu.x) * is.x * ga.x + be.x, (xx.y - mu.y) * is.y * ga.y + be.y,
+                               (xx.z - mu.z) * is.z * ga.z + be.z, (xx.w - mu.w) * is.w * ga.w + be.w);
+        if (res) {
+            const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + c);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+    }
+}
+
+// dx = gamma*invstd*(dy' - [sum_dy/n + xhat*sum_dyx/n]) ; dres = dy'
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ y, int ldy, Coef k,
+                                                           const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
+                                                           float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
+                                                           long long total4, int c4, int relu, int training, float inv_n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        if (relu) {
+            const float4 yy = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (dres) *reinterpret_cast<float4*>(dres + r * lddres + c) = g;
+        const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
+        float4 o;
+        if (training) {
+            const float4 xx = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float4 mu = *reinterpret_cast<const float4*>(k.mean + c);
+            const float4 s1 = *reinterpret_cast<const float4*>(sum_dy + c);
+            const float4 s2 = *reinterpret_cast<const float4*>(sum_dyx + c);
+            o.x = ga.x * is.x * (g.x - inv_n * (s1.x + (xx.x - mu.x) * is.x * s2.x));
+            o.y = ga.y * is.y * (g.y - inv_n * (s1.y + (xx.y - mu.y) * is.y * s2.y));
+            o.z = ga.z * is.z * (g.z - inv_n * (s1.z + (xx.z - mu.z) * is.z * s2.z));
+            o.w = ga.w * is.w * (g.w - inv_n * (s1.w + (xx.w - mu.w) * is.w * s2.w));
+        } else {
+            o = make_float4(g.x * ga.x * is.x, g.y * ga.y * is.y, g.z * ga.z * is.z, g.w * ga.w * is.w);
+        }
+        *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+    }
+}
+
+// ---- TPAVI tail: one wavefront per row ---------------------------------------------------
+constexpr int LN_NV = 8;      // float4 per lane => C <= 64*4*8 = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_res_ln_kernel(const float* __restrict__ w, const float* __restrict__ x, Coef bn,
+                                                        const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
+                                                        float* __restrict__ z, float* __restrict__ row_mean, float* __restrict__ row_rstd,
+                                                        const float* __restrict__ dz, float* __restrict__ du, int rows, int c) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c4 = c >> 2;
+    const long long base = (long long)row * c;
+    float4 u[LN_NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_NV; ++v) {
+        const int cc = lane + 64 * v;
+        if (cc < c4) {
+            const int ch = cc * 4;
+            const float4 ww = *reinterpret_cast<const float4*>(w + base + ch);
+            const float4 xx = *reinterpret_cast<const float4*>(x + base + ch);
+            const float4 mu = *reinterpret_cast<const float4*>(bn.mean + ch);
+            const float4 is = *reinterpret_cast<const float4*>(bn.invstd + ch);
+            const float4 ga = *reinterpret_cast<const float4*>(bn.gamma + ch);
+            const float4 be = *reinterpret_cast<const float4*>(bn.beta + ch);
+            u[v] = make_float4((ww.x - mu.x) * is.x * ga.x + be.x + xx.x, (ww.y - mu.y) * is.y * ga.y + be.y + xx.y,
+                               (ww.z - mu.z) * is.z * ga.z + be.z + xx.z, (ww.w - mu.w) * is.w * ga.w + be.w + xx.w);
+            s += (u[v].x + u[v].y) + (u[v].z + u[v].w);
+        } else {
+            u[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float mean, rstd;
+    if (!BWD) {
+        mean = wave_sum(s) / c;
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_NV; ++v)
+            if (lane + 64 * v < c4) {
+                const float a = u[v].x - mean, b = u[v].y - mean, cc2 = u[v].z - mean, d = u[v].w - mean;
+                q += (a * a + b * b) + (cc2 * cc2 + d * d);
+            }
+        rstd = 1.0f / sqrtf(wave_sum(q) / c + eps);
+        if (lane == 0) { row_mean[row] = mean; row_rstd[row] = rstd; }
+#pragma unroll
+        for (int v = 0; v < LN_NV; ++v) {
+            const int cc = lane + 64 * v;
+            if (cc < c4) {
+                const int ch = cc * 4;
+                const float4 g = *reinterpret_cast<const float4*>(ln_g + ch);
+                const float4 b = *reinterpret_cast<const float4*>(ln_b + ch);
+                *reinterpret_cast<float4*>(z + base + ch) =
+                    make_float4((u[v].x - mean) * rstd * g.x + b.x, (u[v].y - mean) * rstd * g.y + b.y,
+                                (u[v].z - mean) * rstd * g.z + b.z, (u[v].w - mean) * rstd * g.w + b.w);
+            }
+        }
+    } else {
+        mean = row_mean[row]; rstd = row_rstd[row];
+        float4 gz[LN_NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < LN_NV; ++v) {
+            const int cc = lane + 64 * v;
+            if (cc < c4) {
+                const int ch = cc * 4;
+                const float4 d = *reinterpret_cast<const float4*>(dz + base + ch);
+                const float4 g = *reinterpret_cast<const float4*>(ln_g + ch);
+                gz[v] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                u[v] = make_float4((u[v].x - mean) * rstd, (u[v].y - mean) * rstd, (u[v].z - mean) * rstd, (u[v].w - mean) * rstd);
+                s1 += (gz[v].x + gz[v].y) + (gz[v].z + gz[v].w);
+                s2 += (gz[v].x * u[v].x + gz[v].y * u[v].y) + (gz[v].z * u[v].z + gz[v].w * u[v].w);
+            } else {
+                gz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float m1 = wave_sum(s1) / c, m2 = wave_sum(s2) / c;
+#pragma unroll
+        for (int v = 0; v < LN_NV; ++v) {
+            const int cc = lane + 64 * v;
+            if (cc < c4)
+                *reinterpret_cast<float4*>(du + base + cc * 4) =
+                    make_float4(rstd * (gz[v].x - m1 - u[v].x * m2), rstd * (gz[v].y - m1 - u[v].y * m2),
+                                rstd * (gz[v].z - m1 - u[v].z * m2), rstd * (gz[v].w - m1 - u[v].w * m2));
+        }
+    }
+}
+
+inline int stream_grid(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    const long long cap = (long long)glf::num_cus() * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <class Op>
+int launch_colreduce(Op op, int rows, int c, double* ws, hipStream_t s) {
+    const int slices = n_slices(rows);
+    hipLaunchKernelGGL((colreduce_kernel<Op>), dim3(slices), dim3(RT), 0, s, op, rows, c, slices, ws);
+    return glf::check_launch("colreduce");
+}
+
+}  // namespace
+
+extern "C" size_t glf_bn_workspace(int rows, int c) {
+    return (size_t)2 * n_slices(rows) * (size_t)(c > 0 ? c : 0) + (size_t)2 * (c > 0 ? c : 0);
+}
+
+#define REQ_C4(c) GLF_REQUIRE((c) > 0 && ((c) % 4) == 0, GLF_ERR_BAD_SHAPE, "channel count must be a positive multiple of 4 (got %d)", (c))
+#define REQ_AL(p, name) GLF_REQUIRE(al16(p), GLF_ERR_BAD_SHAPE, name " must be 16-byte aligned")
+#define REQ_LD(ld, name) GLF_REQUIRE(((ld) % 4) == 0, GLF_ERR_BAD_SHAPE, name " must be a multiple of 4")
+
+extern "C" int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps, float momentum,
+                            float* mean, float* invstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, double* workspace, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && mean && invstd && workspace, GLF_ERR_NULL, "bn_stats: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_stats: rows must be > 0");
+    REQ_C4(c); REQ_AL(x, "x"); REQ_LD(ldx, "ldx");
+    GLF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GLF_ERR_NULL, "bn_stats: running_mean/var must both be set or both NULL");
+    if (int rc = launch_colreduce(OpStats{x, ldx}, rows, c, workspace, glf::S(s))) return rc;
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, rows,
+                       eps, momentum, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
+    return glf::check_launch("bn_stats_finalize");
+}
+
+extern "C" int glf_bn_eval_coeffs(const float* rm, const float* rv, float eps, float* mean, float* invstd, int c, glf_stream_t s) {
+    GLF_REQUIRE(rm && rv && mean && invstd, GLF_ERR_NULL, "bn_eval_coeffs: null argument");
+    GLF_REQUIRE(c > 0, GLF_ERR_BAD_SHAPE, "bn_eval_coeffs: c must be > 0");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), rm, rv, eps, mean, invstd, c);
+    return glf::check_launch("bn_eval_coeffs");
+}
+
+extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            int rows, int c, int relu, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && y && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply: rows must be > 0");
+    REQ_C4(c); REQ_AL(x, "x"); REQ_AL(y, "y"); REQ_LD(ldx, "ldx"); REQ_LD(ldy, "ldy");
+    if (residual) { REQ_AL(residual, "residual"); REQ_LD(ldr, "ldr"); }
+    const long long total4 = (long long)rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), x, ldx, residual, ldr, y, ldy,
+                       Coef{mean, invstd, gamma, beta}, total4, c / 4, relu);
+    return glf::check_launch("bn_apply");
+}
+
+extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
+                          const float* mean, const float* invstd, const float* gamma,
+                          float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
+                          int rows, int c, int relu, int training, double* workspace, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
+    GLF_REQUIRE(!relu || y, GLF_ERR_NULL, "bn_bwd: y is required when relu != 0");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_bwd: rows must be > 0");
+    REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
+    if (relu) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
+    if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
+    const int slices = n_slices(rows);
+    if (int rc = launch_colreduce(OpBnBwd{dy, lddy, x, ldx, y, ldy, mean, invstd, relu}, rows, c, workspace, glf::S(s))) return rc;
+    // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
+    float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
+    float* s_dy = dbeta ? dbeta : sums;
+    float* s_dyx = dgamma ? dgamma : sums + c;
+    hipLaunchKernelGGL(sum_finalize, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), workspace, slices, c, s_dy, s_dyx);
+    if (int rc = glf::check_launch("bn_bwd_finalize")) return rc;
+    const long long total4 = (long long)rows * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
+                       Coef{mean, invstd, gamma, nullptr}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
+                       1.0f / (float)rows);
+    return glf::check_launch("bn_bwd_apply");
+}
+
+extern "C" int glf_colsum(const float* dy, int lddy, float* db, int rows, int c, double* workspace, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(dy && db && workspace, GLF_ERR_NULL, "colsum: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "colsum: rows must be > 0");
+    REQ_C4(c); REQ_AL(dy, "dy"); REQ_LD(lddy, "lddy");
+    if (int rc = launch_colreduce(OpColsum{dy, lddy}, rows, c, workspace, glf::S(s))) return rc;
+    hipLaunchKernelGGL(sum_finalize, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, db, (float*)nullptr);
+    return glf::check_launch("colsum_finalize");
+}
+
+extern "C" int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn_mean, const float* bn_invstd,
+                                 const float* bn_gamma, const float* bn_beta, const float* ln_gamma,
+                                 const float* ln_beta, float ln_eps, float* z, float* row_mean, float* row_rstd,
+                                 int rows, int c, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(w && x && bn_mean && bn_invstd && bn_gamma && bn_beta && ln_gamma && ln_beta && z && row_mean && row_rstd,
+                GLF_ERR_NULL, "bn_res_ln_fwd: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_res_ln_fwd: rows must be > 0");
+    REQ_C4(c); GLF_REQUIRE(c <= 64 * 4 * LN_NV, GLF_ERR_UNSUPPORTED, "bn_res_ln: C must be <= %d", 64 * 4 * LN_NV);
+    REQ_AL(w, "w"); REQ_AL(x, "x"); REQ_AL(z, "z");
+    hipLaunchKernelGGL((bn_res_ln_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, glf::S(s), w, x,
+                       Coef{bn_mean, bn_invstd, bn_gamma, bn_beta}, ln_gamma, ln_beta, ln_eps, z, row_mean, row_rstd,
+                       (const float*)nullptr, (float*)nullptr, rows, c);
+    return glf::check_launch("bn_res_ln_fwd");
+}
+
+extern "C" int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x, const float* bn_mean,
+                                 const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                 const float* ln_gamma, const float* row_mean, const float* row_rstd,
+                                 float* du, float* dln_gamma, float* dln_beta, int rows, int c,
+                                 double* workspace, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(dz && w && x && bn_mean && bn_invstd && bn_gamma && bn_beta && ln_gamma && row_mean && row_rstd && du &&
+                dln_gamma && dln_beta && workspace, GLF_ERR_NULL, "bn_res_ln_bwd: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_res_ln_bwd: rows must be > 0");
+    REQ_C4(c); GLF_REQUIRE(c <= 64 * 4 * LN_NV, GLF_ERR_UNSUPPORTED, "bn_res_ln: C must be <= %d", 64 * 4 * LN_NV);
+    REQ_AL(dz, "dz"); REQ_AL(w, "w"); REQ_AL(x, "x"); REQ_AL(du, "du");
+    const Coef bn{bn_mean, bn_invstd, bn_gamma, bn_beta};
+    hipLaunchKernelGGL((bn_res_ln_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, glf::S(s), w, x, bn, ln_gamma,
+                       (const float*)nullptr, 0.f, (float*)nullptr, const_cast<float*>(row_mean), const_cast<float*>(row_rstd),
+                       dz, du, rows, c);
+    if (int rc = glf::check_launch("bn_res_ln_bwd")) return rc;
+    if (int rc = launch_colreduce(OpLnParam{dz, w, x, bn, row_mean, row_rstd, c}, rows, c, workspace, glf::S(s))) return rc;
+    hipLaunchKernelGGL(sum_finalize, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, dln_gamma, dln_beta);
+    return glf::check_launch("ln_param_finalize");
+}

@@ -1,0 +1,159 @@
+"""The Global-Local cross-view attention block (TPAVIModule.forward, reference
+models/ours.py:845-917) as ONE autograd node over the HIP contraction engine.
+
+x is [N, V, h, w, C] channels-last, i.e. the matrix [N*L, C] with L = V*h*w positions per
+frame (what the reference builds with unsqueeze(2)+cat(dim=2), ours.py:1819-1820).
+
+mode 'dot' (the shipped model, ours.py:1746-1747):  f = theta^T phi, y = (f / L) g.  It is linear,
+so we re-associate exactly:  M_n = phi_n^T g_n / L  ([Ci,Ci] per frame), y_n = theta_n M_n.  The
+[N,L,L] score matrix (1.4 GB at config 2, 983 MB *per frame* at the 5-view 224^2 config) is never
+formed and the matmul work drops from 2*L*L*Ci to 2*L*Ci*Ci MACs per frame.
+mode 'embedded' (softmax, ours.py:896-897): scores are materialised per frame, normalised by a
+row-softmax kernel, then contracted with g.
+
+Tail (ours.py:908-915): w = W_z y + b;  z = LayerNorm_C( BatchNorm3d(w) + x ) in one fused pass.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import check, lib
+from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, colsum, gemm
+
+
+class TpaviFn(Function):
+    @staticmethod
+    def forward(ctx, x, th_w, th_b, ph_w, ph_b, g_w, g_b, wz_w, wz_b, bn_g, bn_b, ln_g, ln_b,
+                rmean, rvar, nbt, training: bool, momentum: float, bn_eps: float, ln_eps: float, mode: str):
+        x = _contig(_chk(x, "TPAVI input"))
+        if x.dim() != 5:
+            raise RuntimeError("TPAVI input must be [N, V, h, w, C]")
+        n, v, h, w_, c = x.shape
+        L = v * h * w_
+        rows = n * L
+        ci = th_w.shape[0]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        W = lambda t: _contig(t.detach()).view(t.shape[0], t.shape[1])       # Conv3d 1x1x1 weight -> [out, in]
+        thW, phW, gW, zW = W(th_w), W(ph_w), W(g_w), W(wz_w)
+
+        th = torch.empty(rows, ci, **f32)
+        ph = torch.empty(rows, ci, **f32)
+        g = torch.empty(rows, ci, **f32)
+        for out, wt, b in ((th, thW, th_b), (ph, phW, ph_b), (g, gW, g_b)):
+            gemm("nt", x, wt, out, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, bias=b)
+
+        y = torch.empty(rows, ci, **f32)
+        if mode == "dot":
+            att = torch.empty(n, ci, ci, **f32)                              # M_n = phi_n^T g_n / L
+            gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=L * ci,
+                 bsc=ci * ci, alpha=1.0 / L)
+            gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
+        elif mode == "embedded":
+            att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T)
+            gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=ci, ldb=ci, ldc=L, batch=n, bsa=L * ci, bsb=L * ci, bsc=L * L)
+            check(lib.glf_softmax_rows(_p(att), n * L, L, _stream()), "softmax_rows")
+            gemm("nn", att, g, y, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=L * ci, bsc=L * ci)
+        else:
+            raise RuntimeError(f"TPAVI mode {mode!r} is not on the path (built: 'dot', 'embedded')")
+
+        wz = torch.empty(rows, c, **f32)
+        gemm("nt", y, zW, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b)
+
+        mean = torch.empty(c, **f32)
+        invstd = torch.empty(c, **f32)
+        if training:
+            check(lib.glf_bn_stats(_p(wz), c, rows, c, bn_eps, momentum, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
+                                   _p(_ws(rows, c, dev)), _stream()), "bn_stats")
+        else:
+            check(lib.glf_bn_eval_coeffs(_p(rmean), _p(rvar), bn_eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
+        z = torch.empty_like(x)
+        rmu = torch.empty(rows, **f32)
+        rrs = torch.empty(rows, **f32)
+        check(lib.glf_bn_res_ln_fwd(_p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(ln_b), ln_eps,
+                                    _p(z), _p(rmu), _p(rrs), rows, c, _stream()), "bn_res_ln_fwd")
+        ctx.save_for_backward(x, th, ph, g, att, y, wz, mean, invstd, rmu, rrs, thW, phW, gW, zW, bn_g, bn_b, ln_g)
+        ctx.cfg = (n, L, c, ci, training, mode, tuple(th_w.shape), tuple(wz_w.shape))
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        (x, th, ph, g, att, y, wz, mean, invstd, rmu, rrs, thW, phW, gW, zW, bn_g, bn_b, ln_g) = ctx.saved_tensors
+        n, L, c, ci, training, mode, pshape, zshape = ctx.cfg
+        rows = n * L
+        dev = dz.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dz = _contig(dz)
+
+        # LayerNorm backward -> du (gradient of u = BN(w) + x); it is also the residual's gradient
+        du = torch.empty(rows, c, **f32)
+        dln_g = torch.empty(c, **f32)
+        dln_b = torch.empty(c, **f32)
+        check(lib.glf_bn_res_ln_bwd(_p(dz), _p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(rmu), _p(rrs),
+                                    _p(du), _p(dln_g), _p(dln_b), rows, c, _p(_ws(rows, c, dev)), _stream()), "bn_res_ln_bwd")
+        # BatchNorm3d backward on w
+        dwz = torch.empty(rows, c, **f32)
+        dbn_g = torch.empty(c, **f32)
+        dbn_b = torch.empty(c, **f32)
+        check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), _p(dwz), c, None, c,
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _stream()), "bn_bwd")
+        # W_z: w = y zW^T + b
+        sp = _tn_split(rows, c, ci, 1)
+        dzW = (torch.empty if sp == 1 else torch.zeros)(c, ci, **f32)
+        gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp)
+        dzb = colsum(dwz, rows, c)
+        dy = torch.empty(rows, ci, **f32)
+        gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
+        del dwz
+
+        dth = torch.empty(rows, ci, **f32)
+        dph = torch.empty(rows, ci, **f32)
+        dg = torch.empty(rows, ci, **f32)
+        bs = L * ci
+        if mode == "dot":
+            # y_n = th_n M_n ;  M_n = ph_n^T g_n / L
+            gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs)
+            dM = torch.empty(n, ci, ci, **f32)
+            gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=bs, bsc=ci * ci)
+            gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+            gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+        else:
+            # y_n = P_n g_n ; P_n = softmax(th_n ph_n^T)
+            dP = torch.empty(n, L, L, **f32)
+            gemm("nt", dy, g, dP, M=L, N=L, K=ci, lda=ci, ldb=ci, ldc=L, batch=n, bsa=bs, bsb=bs, bsc=L * L)
+            gemm("tn", att, dy, dg, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
+            check(lib.glf_softmax_rows_bwd(_p(att), _p(dP), n * L, L, _stream()), "softmax_rows_bwd")   # dP <- dS
+            gemm("nn", dP, ph, dth, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
+            gemm("tn", dP, th, dph, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
+            del dP
+        del dy
+
+        # projections: out = x W^T + b
+        sp = _tn_split(rows, ci, c, 1)
+        grads_w, grads_b = [], []
+        dx = du                                              # residual gradient, accumulated in place
+        for d, Wm in ((dth, thW), (dph, phW), (dg, gW)):
+            dW = (torch.empty if sp == 1 else torch.zeros)(ci, c, **f32)
+            gemm("tn", d, x, dW, M=ci, N=c, K=rows, lda=ci, ldb=c, ldc=c, split=sp)
+            grads_w.append(dW.view(pshape))
+            grads_b.append(colsum(d, rows, ci))
+            gemm("nn", d, Wm, dx, M=rows, N=c, K=ci, lda=ci, ldb=c, ldc=c, accumulate=True)
+        dx = dx.view_as(x)
+        return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], dzW.view(zshape), dzb,
+                dbn_g, dbn_b, dln_g, dln_b, None, None, None, None, None, None, None, None)
+
+
+def tpavi_forward(x5: torch.Tensor, mod) -> torch.Tensor:
+    """x5: [N, V, h, w, C]; mod: a models.ours.TPAVIModule (parameter container)."""
+    bn = mod.W_z[1]
+    training = bn.training
+    if training and bn.momentum is None:
+        raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")
+    return TpaviFn.apply(
+        x5, mod.theta.weight, mod.theta.bias, mod.phi.weight, mod.phi.bias, mod.g.weight, mod.g.bias,
+        mod.W_z[0].weight, mod.W_z[0].bias, bn.weight, bn.bias, mod.norm_layer.weight, mod.norm_layer.bias,
+        bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None,
+        training, float(bn.momentum or 0.0), float(bn.eps), float(mod.norm_layer.eps), mod.mode)

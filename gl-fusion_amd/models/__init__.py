@@ -1,0 +1,7 @@
+"""Host-side mirror of the reference's ``models`` package for the hot path: same module
+names, constructor signatures, forward contracts and state_dict keys
+(GLfusion/models/{ours,segmentation,deeplabv3,_utils}.py), every forward running on the HIP
+engine."""
+from .ours import Global_and_Local, TPAVIModule  # noqa: F401
+from .segmentation import deeplabv3_resnet50_iekd  # noqa: F401
+from .deeplabv3 import ASPP, DeepLabHead  # noqa: F401

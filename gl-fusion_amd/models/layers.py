@@ -1,0 +1,83 @@
+"""nn.Module leaves with the reference's parameter names and default initialisation, whose
+forward runs on the HIP engine.  They subclass the torch modules only to inherit parameter
+registration / state_dict behaviour; no torch compute kernel is used in forward.
+
+Convention between these modules: tensors are NCHW-shaped with channels_last strides
+(ops.from_nhwc), so they look like ordinary torch tensors to callers while the kernels see
+row-major [N*H*W, C] matrices.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _one(v) -> int:
+    if isinstance(v, (tuple, list)):
+        if any(int(e) != int(v[0]) for e in v):
+            raise RuntimeError(f"glfusion_amd: anisotropic conv/pool parameter {v} is not on the path")
+        return int(v[0])
+    return int(v)
+
+
+class Conv2d(nn.Conv2d):
+    def _geom(self):
+        if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise RuntimeError("glfusion_amd: only groups=1, zero padding convolutions are on the path")
+        return _one(self.stride), _one(self.padding), _one(self.dilation)
+
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        stride, pad, dil = self._geom()
+        if self.in_channels == 1 and self.kernel_size == (7, 7) and stride == 1 and dil == 1:
+            return ops.stem7x7(x, self.weight, self.bias, pad)          # models/_utils.py:192
+        if self.in_channels % 4 != 0:
+            raise RuntimeError(f"glfusion_amd: conv with Cin={self.in_channels} is not on the path")
+        return ops.conv2d(x, self.weight, self.bias, stride, pad, dil)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def forward_nhwc(self, x, relu: bool = False, residual=None):
+        return ops.batch_norm_act(x, self, relu, residual)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
+
+
+class ReLU(nn.ReLU):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.from_nhwc(ops.relu(ops.to_nhwc(x)))
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward_nhwc(self, x):
+        if (_one(self.kernel_size), _one(self.stride), _one(self.padding), _one(self.dilation)) != (3, 2, 1, 1) or self.ceil_mode:
+            raise RuntimeError("glfusion_amd: only MaxPool2d(3, stride=2, padding=1) is on the path")
+        return ops.maxpool3x3s2(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
+
+
+class Dropout(nn.Dropout):
+    def forward_nhwc(self, x):
+        return ops.dropout(x, self.p, self.training)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _one(self.output_size) != 1:
+            raise RuntimeError("glfusion_amd: only AdaptiveAvgPool2d(1) is on the path")
+        return ops.from_nhwc(ops.global_avgpool(ops.to_nhwc(x)))
+
+
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
+    """conv -> BatchNorm (train or eval) -> (+residual) -> (ReLU) on NHWC tensors."""
+    return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual)

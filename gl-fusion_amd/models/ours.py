@@ -1,0 +1,130 @@
+"""Global_and_Local / TPAVIModule of the reference (GLfusion/models/ours.py:1708-1843, 770-917)
+with identical constructor signatures, return contracts and state_dict keys, every forward
+running on the MI355X HIP engine (no torch compute kernels on the path)."""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Sequence
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..fusion import tpavi_forward
+from .layers import Conv2d, conv_bn_act
+from .segmentation import deeplabv3_resnet50_iekd
+
+
+class TPAVIModule(nn.Module):
+    """ours.py:770-917.  Built modes: 'dot' (shipped) and 'embedded' (softmax); dimension=3,
+    bn_layer=True.  forward(x [N,C,V,h,w]) -> (z [N,C,V,h,w], audio_temp=0)."""
+
+    def __init__(self, in_channels: int, inter_channels=None, mode: str = "dot", dimension: int = 3, bn_layer: bool = True) -> None:
+        super().__init__()
+        if mode not in ("gaussian", "embedded", "dot", "concatenate"):
+            raise ValueError("`mode` must be one of `gaussian`, `embedded`, `dot` or `concatenate`")
+        if mode not in ("dot", "embedded") or dimension != 3 or not bn_layer:
+            raise NotImplementedError("glfusion_amd builds TPAVIModule for mode in {'dot','embedded'}, dimension=3, bn_layer=True")
+        self.mode, self.dimension = mode, dimension
+        self.in_channels = in_channels
+        self.inter_channels = inter_channels
+        if self.inter_channels is None:
+            self.inter_channels = in_channels // 2 or 1
+        ci = self.inter_channels
+        # registration order == the reference's (state_dict key order): align_channel, norm_layer, g, W_z, theta, phi
+        self.align_channel = nn.Linear(128, in_channels)        # dead for this model (audio branch)
+        self.norm_layer = nn.LayerNorm(in_channels)
+        self.g = nn.Conv3d(in_channels, ci, kernel_size=1)
+        self.W_z = nn.Sequential(nn.Conv3d(ci, in_channels, kernel_size=1), nn.BatchNorm3d(in_channels))
+        nn.init.constant_(self.W_z[1].weight, 0)
+        nn.init.constant_(self.W_z[1].bias, 0)
+        self.theta = nn.Conv3d(in_channels, ci, kernel_size=1)
+        self.phi = nn.Conv3d(in_channels, ci, kernel_size=1)
+
+    def forward_nvhwc(self, x5: torch.Tensor) -> torch.Tensor:
+        """x5: [N, V, h, w, C] channels-last."""
+        return tpavi_forward(x5, self)
+
+    def forward(self, x: torch.Tensor, audio=None):
+        if audio is not None:
+            raise NotImplementedError("the audio branch (ours.py:855-861) is not on the path")
+        ops._chk(x, "TPAVI input")
+        x5 = x.permute(0, 2, 3, 4, 1)
+        x5 = x5 if x5.is_contiguous() else x5.contiguous()
+        return self.forward_nvhwc(x5).permute(0, 4, 1, 2, 3), 0
+
+
+class Global_and_Local(nn.Module):
+    """ours.py:1708-1843."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__()
+        self.outchannel_list = {"1": 2, "2": 1, "3": 2, "4": 4}
+        self.view_num = view_num
+        self.test_view = test_view
+        self.center_aware_weight = center_aware_weight
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)
+        self.init_block = nn.ModuleDict()
+        self.layer1 = nn.ModuleDict()
+        self.layer2 = nn.ModuleDict()
+        self.layer3 = nn.ModuleDict()
+        self.layer4 = nn.ModuleDict()
+        self.classifier = nn.ModuleDict()
+        self.centerness = nn.ModuleDict()
+        bb = self.network.backbone
+        for view in self.view_num:
+            self.init_block[view] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            self.layer1[view] = copy.deepcopy(bb["layer1"])
+            self.layer2[view] = copy.deepcopy(bb["layer2"])
+            self.layer3[view] = copy.deepcopy(bb["layer3"])
+            self.layer4[view] = copy.deepcopy(bb["layer4"])
+            self.classifier[view] = copy.deepcopy(self.network.classifier)
+            last = self.network.classifier[-1]
+            self.classifier[view][-1] = Conv2d(last.in_channels, 5, kernel_size=last.kernel_size)
+            self.centerness[view] = copy.deepcopy(self.network.classifier)
+            self.centerness[view][-1] = Conv2d(last.in_channels, 1, kernel_size=last.kernel_size)
+        self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
+        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
+
+    # -- encoder (ours.py:1795-1800) -------------------------------------------------------
+    def _encode(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        f4 = {}
+        for view in self.view_num:
+            blk = self.init_block[view]
+            f = conv_bn_act(ops.to_nhwc(x[view]), blk[0], blk[1], relu=True)
+            f = blk[3].forward_nhwc(f)
+            f = self.layer1[view].forward_nhwc(f)
+            f = self.layer2[view].forward_nhwc(f)
+            f = self.layer3[view].forward_nhwc(f)
+            f4[view] = self.layer4[view].forward_nhwc(f)
+        return f4
+
+    def backbone(self, x):
+        """ours.py:1749-1773: per-view encoder + classifier, no fusion."""
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self._encode(x)
+        mask = {v: ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), int(hw[0]), int(hw[1])) for v in self.view_num}
+        return mask, {v: ops.from_nhwc(f) for v, f in f4.items()}
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        views = list(self.view_num)
+        hw = x[views[0]].shape[-2:]
+        ho, wo = int(hw[0]), int(hw[1])
+        f4 = self._encode(x)
+        # M_cls, M_ctr, local features (ours.py:1802-1816)
+        f4_local = {}
+        for v in views:
+            cls = self.classifier[v].forward_nhwc(f4[v])
+            ctr = self.centerness[v].forward_nhwc(f4[v])
+            f4_local[v] = ops.local_gate(cls, ctr, f4[v], self.center_aware_weight)
+        # global / local cross-view fusion (ours.py:1819-1830)
+        g_out = self.global_attn.forward_nvhwc(ops.stack_views([f4[v] for v in views]))        # [N,V,h,w,C]
+        l_out = self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))
+        fused = ops.add_views(g_out, l_out)                                                     # ours.py:1833-1834
+        mask, mask_bb, f4_g, f4_l = {}, {}, {}, {}
+        for i, v in enumerate(views):
+            f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)       # == global_conv_feat[:, :, i, :, :]
+            f4_l[v] = l_out[:, i].permute(0, 3, 1, 2)
+            mask[v] = ops.bilinear_up(self.classifier[v].forward_nhwc(fused[i]), ho, wo)        # ours.py:1837-1838
+            mask_bb[v] = ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), ho, wo)        # ours.py:1840-1841
+        return mask, mask_bb, f4_g, f4_l

@@ -1,0 +1,707 @@
+"""torch.autograd.Function wrappers over the C ABI (include/glfusion.h).
+
+Every function here launches hand-written gfx950 kernels from libglfusion_hip.so on
+PyTorch's current HIP stream.  PyTorch is used for device memory (torch.empty / zeros),
+views and the autograd graph only.  Inputs that are not CUDA float32 tensors raise: there
+is no CPU or eager fallback on the product path.
+
+Internal layout: activations are channels-last, carried as contiguous [N, H, W, C]
+tensors (== the row-major matrix [N*H*W, C] the kernels see).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import GemmParams, check, lib
+
+
+# ----------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(
+            f"glfusion_amd: {name} must be a CUDA(HIP) float32 tensor (got "
+            f"{getattr(t, 'device', None)}, {getattr(t, 'dtype', None)}). The engine has no CPU fallback.")
+    return t
+
+
+def _contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(rows: int, c: int, dev) -> torch.Tensor:
+    return torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=dev)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped tensor (any strides) -> contiguous [N,H,W,C]; free for channels_last / C == 1."""
+    _chk(x, "input")
+    if x.dim() != 4:
+        raise RuntimeError(f"expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
+    n, c, h, w = x.shape
+    if c == 1:
+        return _contig(x).reshape(n, h, w, 1)
+    xp = x.permute(0, 2, 3, 1)
+    return xp if xp.is_contiguous() else xp.contiguous()
+
+
+def from_nhwc(y: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,C] -> NCHW-shaped view with channels_last strides (zero-copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------------------
+# contraction front-end
+# ----------------------------------------------------------------------------------------
+def _axis_valid_fwd(hd: int, hs: int, k: int, stride: int, pad: int, dil: int) -> List[bool]:
+    return [any(0 <= y * stride - pad + t * dil < hs for y in range(hd)) for t in range(k)]
+
+
+def _axis_valid_bwd(hd: int, hs: int, k: int, stride: int, pad: int, dil: int) -> List[bool]:
+    out = []
+    for t in range(k):
+        ok = False
+        for y in range(hd):
+            v = y + pad - t * dil
+            if v >= 0 and v % stride == 0 and v // stride < hs:
+                ok = True
+                break
+        out.append(ok)
+    return out
+
+
+_mask_cache = {}
+
+
+def tap_mask(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, stride: int, pad: int, dil: int) -> int:
+    key = (gather, hd, wd, hs, ws, kh, kw, stride, pad, dil)
+    m = _mask_cache.get(key)
+    if m is None:
+        f = _axis_valid_fwd if gather == 1 else _axis_valid_bwd
+        vy, vx = f(hd, hs, kh, stride, pad, dil), f(wd, ws, kw, stride, pad, dil)
+        m = 0
+        for ky in range(kh):
+            for kx in range(kw):
+                if vy[ky] and vx[kx]:
+                    m |= 1 << (ky * kw + kx)
+        _mask_cache[key] = m
+    return m
+
+
+def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: int, N: int, K: int,
+         lda: int, ldb: int, ldc: int, bias: Optional[torch.Tensor] = None, taps: int = 1, mask: int = 1,
+         tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
+         bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
+         split: int = 1) -> None:
+    """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil)."""
+    p = GemmParams()
+    p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+    p.taps, p.tap_mask, p.tap_stride_b, p.gather = taps, mask, tap_stride_b, gather
+    if geo is not None:
+        (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = geo
+    else:
+        (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
+    p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
+    p.alpha, p.accumulate, p.split = alpha, int(accumulate), split
+    if mode == "nt":
+        check(lib.glf_gemm_nt(_p(A), _p(B), _p(bias), _p(Cm), C.byref(p), _stream()), "gemm_nt")
+    elif mode == "nn":
+        check(lib.glf_gemm_nn(_p(A), _p(B), _p(bias), _p(Cm), C.byref(p), _stream()), "gemm_nn")
+    elif mode == "tn":
+        check(lib.glf_gemm_tn(_p(A), _p(B), _p(Cm), C.byref(p), _stream()), "gemm_tn")
+    else:
+        raise ValueError(mode)
+
+
+def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
+    """Reduction slices for the TN (wgrad) kernel: fill ~4 waves of 512 resident workgroups,
+    keep >= 16 K-tiles (512 rows) per slice."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128) * max(ntaps, 1) * batch
+    want = max(1, (2048 + tiles - 1) // tiles)
+    cap = max(1, rows // 512)
+    return int(max(1, min(want, cap, 65535 // max(batch, 1))))
+
+
+def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
+    """db[c] = sum_r dy[r][c] (bias gradients)."""
+    db = torch.empty(c, dtype=torch.float32, device=dy2d.device)
+    if c % 4 == 0:
+        check(lib.glf_colsum(_p(dy2d), c, _p(db), rows, c, _p(_ws(rows, c, dy2d.device)), _stream()), "colsum")
+    else:
+        # tiny channel counts (the 5- and 1-channel heads): reduce with the TN contraction against a
+        # broadcast 1.0 (row stride 0)
+        one = torch.ones(4, dtype=torch.float32, device=dy2d.device)
+        db.zero_()
+        gemm("tn", dy2d, one, db, M=c, N=1, K=rows, lda=c, ldb=0, ldc=1, split=_tn_split(rows, c, 1, 1))
+    return db
+
+
+# weight re-layout cache: OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes
+_wt_cache = {}
+
+
+def tap_major(weight: torch.Tensor) -> torch.Tensor:
+    co, ci, kh, kw = weight.shape
+    if kh * kw == 1:
+        return _contig(weight.detach()).view(1, co, ci)
+    key = id(weight)
+    hit = _wt_cache.get(key)
+    if hit is not None and hit[0] == weight._version and hit[2] == weight.data_ptr() and hit[1].shape == (kh * kw, co, ci):
+        return hit[1]
+    wt = torch.empty(kh * kw, co, ci, dtype=torch.float32, device=weight.device)
+    check(lib.glf_oihw_to_tap_major(_p(_contig(weight.detach())), _p(wt), co, ci, kh * kw, _stream()), "oihw_to_tap_major")
+    _wt_cache[key] = (weight._version, wt, weight.data_ptr())
+    return wt
+
+
+# ----------------------------------------------------------------------------------------
+# conv2d (NHWC, implicit GEMM)
+# ----------------------------------------------------------------------------------------
+def _conv_out(h: int, k: int, stride: int, pad: int, dil: int) -> int:
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+class Conv2dFn(Function):
+    """F.conv2d on [N,H,W,Cin] with torch-layout weights [Cout,Cin,kh,kw] (groups = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int):
+        _chk(x, "conv input"); _chk(weight, "conv weight")
+        x = _contig(x)
+        n, h, w, cin = x.shape
+        cout, cin_w, kh, kw = weight.shape
+        if cin_w != cin:
+            raise RuntimeError(f"conv2d: input has {cin} channels, weight expects {cin_w}")
+        ho, wo = _conv_out(h, kh, stride, pad, dil), _conv_out(w, kw, stride, pad, dil)
+        if ho <= 0 or wo <= 0:
+            raise RuntimeError("conv2d: empty output")
+        taps = kh * kw
+        wt = tap_major(weight)
+        y = torch.empty(n, ho, wo, cout, dtype=torch.float32, device=x.device)
+        plain = taps == 1 and stride == 1 and pad == 0
+        geo = (n, h, w, ho, wo, kh, kw, stride, pad, dil)
+        mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+        gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
+             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo)
+        ctx.save_for_backward(x, wt)
+        ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, has_bias, wshape = ctx.cfg
+        dy = _contig(dy)
+        taps = kh * kw
+        rows_o = n * ho * wo
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            mask = 1 if plain else tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
+            if mask == 0:
+                dx = torch.zeros_like(x)
+            else:
+                dx = torch.empty_like(x)
+                gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+                     tap_stride_b=cout * cin, gather=0 if plain else 2,
+                     geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil))
+        if ctx.needs_input_grad[1]:
+            mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+            ntap = bin(mask).count("1")
+            split = _tn_split(rows_o, cout, cin, ntap)
+            full = mask == (1 << taps) - 1
+            dwt = (torch.empty if (split == 1 and full) else torch.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
+            gemm("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+                 tap_stride_b=cout * cin, gather=0 if plain else 1,
+                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split)
+            if taps == 1:
+                dw = dwt.view(wshape)
+            else:
+                dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+                check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, rows_o, cout)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1):
+    return Conv2dFn.apply(x, weight, bias, stride, pad, dil)
+
+
+class ConvCatFn(Function):
+    """1x1 conv over the channel-concatenation of several [N,H,W,Ck] inputs WITHOUT materialising
+    the concat (ASPP project, deeplabv3.py:153-165): y = sum_k x_k @ W[:, slice_k]^T."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        _chk(weight, "weight")
+        xs = [_contig(_chk(t, "input")) for t in xs]
+        cout, ctot = weight.shape[0], weight.shape[1]
+        w2 = _contig(weight.detach()).view(cout, ctot)
+        rows = xs[0].numel() // xs[0].shape[-1]
+        y = torch.empty(*xs[0].shape[:-1], cout, dtype=torch.float32, device=xs[0].device)
+        off = 0
+        for i, t in enumerate(xs):
+            ck = t.shape[-1]
+            gemm("nt", t, w2[:, off:], y, M=rows, N=cout, K=ck, lda=ck, ldb=ctot, ldc=cout, accumulate=i > 0)
+            off += ck
+        if off != ctot:
+            raise RuntimeError(f"conv_cat: inputs have {off} channels in total, weight expects {ctot}")
+        ctx.save_for_backward(w2, *xs)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        w2, *xs = ctx.saved_tensors
+        dy = _contig(dy)
+        cout, ctot = w2.shape
+        rows = dy.numel() // cout
+        split = _tn_split(rows, cout, xs[0].shape[-1], 1)
+        dw = None
+        if ctx.needs_input_grad[0]:
+            dw = (torch.empty if split == 1 else torch.zeros)(cout, ctot, dtype=torch.float32, device=dy.device)
+        grads = []
+        off = 0
+        for i, t in enumerate(xs):
+            ck = t.shape[-1]
+            if ctx.needs_input_grad[1 + i]:
+                dx = torch.empty_like(t)
+                gemm("nn", dy, w2[:, off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=ctot, ldc=ck)
+                grads.append(dx)
+            else:
+                grads.append(None)
+            if dw is not None:
+                gemm("tn", dy, t, dw[:, off:], M=cout, N=ck, K=rows, lda=cout, ldb=ck, ldc=ctot, split=split)
+            off += ck
+        return (dw.view(ctx.wshape) if dw is not None else None, *grads)
+
+
+def conv1x1_cat(weight, xs: Sequence[torch.Tensor]):
+    return ConvCatFn.apply(weight, *xs)
+
+
+# ----------------------------------------------------------------------------------------
+# stem: Conv2d(1, 64, 7, stride 1, pad p) + bias   (models/_utils.py:192)
+# ----------------------------------------------------------------------------------------
+class StemFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad: int):
+        _chk(x, "stem input"); _chk(weight, "stem weight")
+        x = _contig(x)                                  # [N,H,W,1]
+        n, h, w, _ = x.shape
+        cout = weight.shape[0]
+        y = torch.empty(n, h + 2 * pad - 6, w + 2 * pad - 6, cout, dtype=torch.float32, device=x.device)
+        check(lib.glf_stem7x7_fwd(_p(x), _p(_contig(weight.detach())), _p(bias), _p(y), n, h, w, cout, pad, _stream()), "stem7x7_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (n, h, w, cout, pad, tuple(weight.shape), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, cout, pad, wshape, has_bias = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("glfusion_amd: gradient w.r.t. the input image is not on the path (stem dgrad not built)")
+        dy = _contig(dy)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dy.device)
+        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if has_bias else None
+        part = torch.empty(int(lib.glf_stem7x7_wgrad_workspace(n, h, w, cout, pad)), dtype=torch.float32, device=dy.device)
+        check(lib.glf_stem7x7_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(part), n, h, w, cout, pad, _stream()), "stem7x7_wgrad")
+        return None, dw, db, None
+
+
+def stem7x7(x, weight, bias, pad: int):
+    return StemFn.apply(x, weight, bias, pad)
+
+
+# ----------------------------------------------------------------------------------------
+# BatchNorm (+ residual, + ReLU)
+# ----------------------------------------------------------------------------------------
+class BatchNormActFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool,
+                momentum: float, eps: float, relu: bool):
+        _chk(x, "bn input"); _chk(gamma, "bn weight"); _chk(beta, "bn bias")
+        x = _contig(x)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dev = x.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        if training:
+            check(lib.glf_bn_stats(_p(x), c, rows, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                                   _p(nbt), _p(_ws(rows, c, dev)), _stream()), "bn_stats")
+        else:
+            if running_mean is None or running_var is None:
+                raise RuntimeError("batch_norm in eval mode needs running statistics")
+            check(lib.glf_bn_eval_coeffs(_p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
+        if residual is not None:
+            residual = _contig(_chk(residual, "bn residual"))
+        y = torch.empty_like(x)
+        check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
+                               int(relu), _stream()), "bn_apply")
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        ctx.cfg = (rows, c, relu, training, residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        rows, c, relu, training, has_res = ctx.cfg
+        dy = _contig(dy)
+        dev = dy.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(dx), c, _p(dres), c,
+                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _stream()), "bn_bwd")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None):
+    """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
+    optionally fused with a residual add and ReLU."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is None and training and bn.track_running_stats:
+        raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")
+    track = training and bn.track_running_stats
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, residual,
+                                bn.running_mean if (track or not training) else None,
+                                bn.running_var if (track or not training) else None,
+                                bn.num_batches_tracked if track else None,
+                                training, momentum, float(bn.eps), relu)
+
+
+# ----------------------------------------------------------------------------------------
+# ReLU / dropout / pooling
+# ----------------------------------------------------------------------------------------
+class ReluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk(x, "relu input"))
+        y = torch.empty_like(x)
+        check(lib.glf_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _contig(dy)
+        dx = torch.empty_like(dy)
+        check(lib.glf_relu_bwd(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "relu_bwd")
+        return dx
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int):
+        x = _contig(_chk(x, "dropout input"))
+        y = torch.empty_like(x)
+        check(lib.glf_dropout(_p(x), _p(y), x.numel(), p, seed, _stream()), "dropout")
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty_like(dy)
+        check(lib.glf_dropout(_p(dy), _p(dx), dy.numel(), p, seed, _stream()), "dropout_bwd")
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        raise RuntimeError("dropout p must be < 1")
+    seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())   # host RNG: no device sync
+    return DropoutFn.apply(x, float(p), seed)
+
+
+class MaxPool3x3s2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk(x, "maxpool input"))
+        n, h, w, c = x.shape
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        y = torch.empty(n, ho, wo, c, dtype=torch.float32, device=x.device)
+        idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=x.device)
+        check(lib.glf_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.cfg = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
+        check(lib.glf_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _stream()), "maxpool_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return MaxPool3x3s2Fn.apply(x)
+
+
+class AvgPoolFn(Function):
+    """AdaptiveAvgPool2d(1): [N,H,W,C] -> [N,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk(x, "avgpool input"))
+        n, h, w, c = x.shape
+        y = torch.empty(n, 1, 1, c, dtype=torch.float32, device=x.device)
+        check(lib.glf_avgpool_fwd(_p(x), _p(y), n, h * w, c, _stream()), "avgpool_fwd")
+        ctx.cfg = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
+        check(lib.glf_bcast_rows_scaled(_p(dy), _p(dx), c, 1.0 / (h * w), n, h * w, c, _stream()), "avgpool_bwd")
+        return dx
+
+
+def global_avgpool(x):
+    return AvgPoolFn.apply(x)
+
+
+class BroadcastFn(Function):
+    """bilinear up-sampling from a 1x1 map == broadcast: [N,1,1,C] -> [N,H,W,C]."""
+
+    @staticmethod
+    def forward(ctx, x, h: int, w: int):
+        x = _contig(_chk(x, "broadcast input"))
+        n, c = x.shape[0], x.shape[-1]
+        y = torch.empty(n, h, w, c, dtype=torch.float32, device=x.device)
+        check(lib.glf_bcast_rows_fwd(_p(x), _p(y), c, n, h * w, c, _stream()), "bcast_rows")
+        ctx.cfg = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(n, 1, 1, c, dtype=torch.float32, device=dy.device)
+        check(lib.glf_sum_rows_fwd(_p(dy), c, _p(dx), 1.0, n, h * w, c, _stream()), "bcast_rows_bwd")
+        return dx, None, None
+
+
+def broadcast_hw(x, h: int, w: int):
+    return BroadcastFn.apply(x, h, w)
+
+
+# ----------------------------------------------------------------------------------------
+# local gate (ours.py:1802-1816)
+# ----------------------------------------------------------------------------------------
+class GateFn(Function):
+    @staticmethod
+    def forward(ctx, cls, ctr, f, weight: float):
+        cls, ctr, f = _contig(_chk(cls, "cls")), _contig(_chk(ctr, "ctr")), _contig(_chk(f, "f4"))
+        c = f.shape[-1]
+        rows = f.numel() // c
+        ncls = cls.shape[-1]
+        y = torch.empty_like(f)
+        a = torch.empty(rows, dtype=torch.float32, device=f.device)
+        am = torch.empty(rows, dtype=torch.int32, device=f.device)
+        check(lib.glf_gate_fwd(_p(cls), ncls, _p(ctr), _p(f), _p(y), _p(a), _p(am), weight, rows, c, _stream()), "gate_fwd")
+        ctx.save_for_backward(cls, ctr, f, a, am)
+        ctx.cfg = (rows, c, ncls, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        cls, ctr, f, a, am = ctx.saved_tensors
+        rows, c, ncls, weight = ctx.cfg
+        dy = _contig(dy)
+        df = torch.empty_like(f)
+        dcls = torch.empty_like(cls)
+        dctr = torch.empty_like(ctr)
+        check(lib.glf_gate_bwd(_p(dy), _p(f), _p(cls), ncls, _p(ctr), _p(a), _p(am), weight, _p(df), _p(dcls), _p(dctr),
+                               rows, c, _stream()), "gate_bwd")
+        return dcls, dctr, df, None
+
+
+def local_gate(cls_logits, ctr_logits, f4, weight: float):
+    return GateFn.apply(cls_logits, ctr_logits, f4, float(weight))
+
+
+# ----------------------------------------------------------------------------------------
+# view stacking / slicing for the fusion block
+# ----------------------------------------------------------------------------------------
+class StackViewsFn(Function):
+    """[N,h,w,C] x V -> [N,V,h,w,C] (ours.py:1819-1820: unsqueeze(2) + cat(dim=2) in NCDHW terms)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_contig(_chk(t, "view feature")) for t in xs]
+        n, h, w, c = xs[0].shape
+        v = len(xs)
+        out = torch.empty(n, v, h, w, c, dtype=torch.float32, device=xs[0].device)
+        inner = h * w * c
+        for i, t in enumerate(xs):
+            check(lib.glf_copy_frames(_p(t), inner, _p(out[:, i]), v * inner, n, inner, _stream()), "stack_views")
+        ctx.cfg = (n, v, h, w, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, v, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            g = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
+            check(lib.glf_copy_frames(_p(dy[:, i]), v * inner, _p(g), inner, n, inner, _stream()), "unstack_views")
+            outs.append(g)
+        return tuple(outs)
+
+
+def stack_views(xs: Sequence[torch.Tensor]):
+    return StackViewsFn.apply(*xs)
+
+
+class AddViewsFn(Function):
+    """f4_fusion[v] = G[:, i] + L[:, i] for every view i of two [N,V,h,w,C] tensors
+    (ours.py:1833-1834); returns V contiguous [N,h,w,C] tensors."""
+
+    @staticmethod
+    def forward(ctx, g, l):
+        g, l = _contig(_chk(g, "global")), _contig(_chk(l, "local"))
+        n, v, h, w, c = g.shape
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            out = torch.empty(n, h, w, c, dtype=torch.float32, device=g.device)
+            check(lib.glf_add_frames(_p(g[:, i]), v * inner, _p(l[:, i]), v * inner, _p(out), inner, n, inner, _stream()), "add_views")
+            outs.append(out)
+        ctx.cfg = (n, v, h, w, c)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        n, v, h, w, c = ctx.cfg
+        inner = h * w * c
+        dev = next(d.device for d in dys if d is not None)
+        dg = torch.empty(n, v, h, w, c, dtype=torch.float32, device=dev)
+        for i, d in enumerate(dys):
+            if d is None:
+                dg[:, i].zero_()
+            else:
+                check(lib.glf_copy_frames(_p(_contig(d)), inner, _p(dg[:, i]), v * inner, n, inner, _stream()), "add_views_bwd")
+        return dg, dg
+
+
+def add_views(g, l):
+    return AddViewsFn.apply(g, l)
+
+
+# ----------------------------------------------------------------------------------------
+# bilinear up-sampling to NCHW logits, loss, metrics
+# ----------------------------------------------------------------------------------------
+class BilinearUpFn(Function):
+    """F.interpolate(mode='bilinear', align_corners=False): [N,h,w,C] -> NCHW [N,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, ho: int, wo: int):
+        x = _contig(_chk(x, "upsample input"))
+        n, h, w, c = x.shape
+        y = torch.empty(n, c, ho, wo, dtype=torch.float32, device=x.device)
+        check(lib.glf_bilinear_up_fwd(_p(x), _p(y), n, h, w, c, ho, wo, _stream()), "bilinear_up_fwd")
+        ctx.cfg = (n, h, w, c, ho, wo)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c, ho, wo = ctx.cfg
+        dy = _contig(_chk(dy, "upsample grad"))
+        dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dy.device)
+        check(lib.glf_bilinear_up_bwd(_p(dy), _p(dx), n, h, w, c, ho, wo, _stream()), "bilinear_up_bwd")
+        return dx, None, None
+
+
+def bilinear_up(x, ho: int, wo: int):
+    return BilinearUpFn.apply(x, ho, wo)
+
+
+class BceSumFn(Function):
+    """nn.BCEWithLogitsLoss(reduction='sum') (main.py:87)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = _contig(_chk(logits, "logits")), _contig(_chk(target, "target"))
+        if logits.shape != target.shape:
+            raise RuntimeError("bce: logits/target shape mismatch")
+        loss = torch.empty(1, dtype=torch.float64, device=logits.device)
+        check(lib.glf_bce_logits_sum(_p(logits), _p(target), _p(loss), None, 1.0, None, logits.numel(), _stream()), "bce_logits_sum")
+        ctx.save_for_backward(logits, target)
+        return loss[0].float()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        logits, target = ctx.saved_tensors
+        dx = torch.empty_like(logits)
+        scratch = torch.empty(1, dtype=torch.float64, device=logits.device)
+        dl = _contig(dl.float())
+        # dx = (sigmoid(x) - t) * upstream, the upstream scalar read on the device (no host sync)
+        check(lib.glf_bce_logits_sum(_p(logits), _p(target), _p(scratch), _p(dx), 1.0, _p(dl), logits.numel(), _stream()), "bce_logits_bwd")
+        return dx, None
+
+
+def bce_with_logits_sum(logits, target):
+    return BceSumFn.apply(logits, target)
+
+
+def overlap_counts(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """int64 [tp, fp, fn, tn] of pred = sigmoid(logits) > 0.5 against target (main.py:800-815)."""
+    logits, target = _contig(_chk(logits, "logits")), _contig(_chk(target, "target"))
+    counts = torch.empty(4, dtype=torch.int64, device=logits.device)
+    check(lib.glf_overlap_counts(_p(logits), _p(target), _p(counts), logits.numel(), _stream()), "overlap_counts")
+    return counts
+
+
+def overlap_metrics_from_counts(counts: torch.Tensor, eps: float = 1e-5):
+    """(pixel_acc, dice, precision, specificity, recall) exactly as main.py:807-813."""
+    tp, fp, fn, tn = [float(v) for v in counts.tolist()]
+    return ((tp + tn) / (tp + tn + fp + fn + eps), (2 * tp) / (2 * tp + fp + fn + eps),
+            tp / (tp + fp + eps), tn / (tn + fp + eps), tp / (tp + fn + eps))

@@ -1,0 +1,214 @@
+/*
+ * glfusion.h -- C ABI of libglfusion_hip.so: the MI355X (gfx950 / CDNA4) engine for the
+ * GL-Fusion forward/backward hot path.
+ *
+ * The reference (xmed-lab/GL-Fusion) is pure PyTorch: it has no FFI of its own.  Each entry
+ * point below replaces the ATen operator(s) the reference launches implicitly at the cited
+ * call sites (file:line relative to GLfusion/ in the reference tree); the Python host side
+ * (gl-fusion_amd/) binds them with ctypes from torch.autograd.Function wrappers.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is CALLER-OWNED (inputs, outputs,
+ *     workspace, saved-for-backward).  The library never allocates or frees device memory
+ *     and keeps no pointer after return.
+ *   - every function only ENQUEUES work on `stream` and returns; no host synchronisation.
+ *   - return 0 on success, a negative glf_status otherwise; text via glf_last_error()
+ *     (thread-local).  No exception crosses this boundary.
+ *   - activations are channels-last: a tensor [N,H,W,C] is the row-major matrix
+ *     [rows = N*H*W][C]; `ld*` arguments are row strides in elements.
+ *   - arithmetic type: fp32 (v_mfma_f32_32x32x2_f32 for every contraction).
+ */
+#ifndef GLFUSION_H
+#define GLFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* glf_stream_t; /* hipStream_t */
+
+typedef enum {
+    GLF_OK = 0,
+    GLF_ERR_BAD_SHAPE = -1,
+    GLF_ERR_UNSUPPORTED = -2,
+    GLF_ERR_WORKSPACE = -3,
+    GLF_ERR_LAUNCH = -4,
+    GLF_ERR_NULL = -5
+} glf_status;
+
+const char* glf_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int glf_abi_version(void);
+/* Queries the current device once (CU count) and raises the dynamic-LDS limit of the MFMA
+ * kernels.  Optional: every entry point calls it lazily. */
+int glf_init(void);
+/* sizeof(glf_gemm_params) as compiled into the library (binding self-check). */
+size_t glf_sizeof_gemm_params(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Contractions (implicit GEMM, NHWC, im2col-free; v_mfma_f32_32x32x2_f32; 128x128x32 tiles
+ * staged through LDS).  One parameter block serves conv forward / dgrad / wgrad and the
+ * plain (batched) GEMMs of the fusion block.
+ *
+ *   C[b][m][n] (+)= alpha * sum_{tap} sum_{k} A_tap[b][m][k] * B_tap[b][k][n]  (+ bias[n])
+ *
+ * gather: 0 = A rows are taken as they are (plain GEMM / 1x1 stride-1 conv)
+ *         1 = forward conv mapping : GEMM row m = output pixel (n,y,x) on the hd x wd grid reads
+ *             source pixel (y*stride - pad + ky*dil, x*stride - pad + kx*dil) on the hs x ws grid
+ *         2 = transposed mapping (dgrad): row m = input pixel (n,y,x) on hd x wd reads the
+ *             output-gradient pixel ((y + pad - ky*dil)/stride, ...) on hs x ws when divisible
+ * Out-of-range taps read zeros; taps invalid for a whole 128-row tile are skipped.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, N, K;            /* per-tap GEMM extents (see each entry point)                   */
+    int32_t lda, ldb, ldc;      /* row strides (elements)                                        */
+    int32_t taps;               /* kh*kw (1 for plain GEMM)                                      */
+    uint32_t tap_mask;          /* bit t set = tap t can be valid for some row (host-computed)   */
+    int64_t tap_stride_b;       /* elements between consecutive taps of the weight operand       */
+    int32_t gather;             /* 0 / 1 / 2 as above                                            */
+    int32_t n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil;
+    int32_t batch;              /* >= 1                                                          */
+    int64_t batch_stride_a, batch_stride_b, batch_stride_c;
+    float alpha;                /* scale applied to the accumulator                              */
+    int32_t accumulate;         /* 1: C += result (fwd/dgrad: read-modify-write; wgrad: atomics) */
+    int32_t split;              /* wgrad/TN only: number of reduction slices (>=1); >1 requires  */
+                                /* C zero-filled (or holding the value to accumulate onto)       */
+} glf_gemm_params;
+
+/* A[m][k] (k contiguous, rows gathered per `gather`), B_tap[n][k] (k contiguous: torch's
+ * [Cout][Cin] weight layout per tap), C[m][n].  Replaces F.conv2d / nn.Conv3d(1x1x1) forward:
+ * models/_utils.py:192 (stem is separate), torchvision Bottleneck convs (ours.py:1797-1800),
+ * deeplabv3.py:104-165, ours.py:866,878-879,908.  bias may be NULL. */
+int glf_gemm_nt(const float* A, const float* B, const float* bias, float* C,
+                const glf_gemm_params* p, glf_stream_t stream);
+/* A[m][k] (rows gathered), B_tap[k][n] (n contiguous), C[m][n].  Conv dgrad (A = dY, B = the
+ * same [tap][Cout][Cin] weights, gather = 2) and y = theta @ M of the re-associated dot
+ * attention (ours.py:881-902). */
+int glf_gemm_nn(const float* A, const float* B, const float* bias, float* C,
+                const glf_gemm_params* p, glf_stream_t stream);
+/* Reduction over ROWS: C_tap[m][n] (+)= alpha * sum_r A[r][m] * B[src(r,tap)][n], r < K.
+ * Here p->K is the number of rows r, p->M / p->N the two channel extents, `gather` applies
+ * to B's rows.  Conv wgrad (A = dY [rows][Cout], B = X [rows][Cin], C = dW [tap][Cout][Cin])
+ * and M = phi^T g of the dot attention.  Output taps are p->tap_stride_b apart in C. */
+int glf_gemm_tn(const float* A, const float* B, float* C,
+                const glf_gemm_params* p, glf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight layout: torch OIHW [Cout][Cin][kh][kw] <-> tap-major [kh*kw][Cout][Cin].
+ * ------------------------------------------------------------------------------------- */
+int glf_oihw_to_tap_major(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
+int glf_tap_major_to_oihw(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
+ * Stem (a2): Conv2d(1,64,7,stride 1,pad 2)+bias (models/_utils.py:192; used ours.py:1796).
+ * x [N][H][W] (C=1), w [Cout][49], y [N][Ho][Wo][Cout] with Ho = H + 2*pad - 6.
+ * ------------------------------------------------------------------------------------- */
+int glf_stem7x7_fwd(const float* x, const float* w, const float* bias, float* y,
+                    int n, int h, int wdt, int cout, int pad, glf_stream_t s);
+/* dW [Cout][49] and db [Cout]; partial must hold glf_stem7x7_wgrad_workspace() floats. */
+size_t glf_stem7x7_wgrad_workspace(int n, int h, int wdt, int cout, int pad);
+int glf_stem7x7_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial,
+                      int n, int h, int wdt, int cout, int pad, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm (nn.BatchNorm2d / BatchNorm3d in train and eval mode), channels-last [rows][C].
+ * ------------------------------------------------------------------------------------- */
+/* number of doubles of workspace for bn_stats / bn_bwd_reduce */
+size_t glf_bn_workspace(int rows, int c);
+/* Batch statistics over `rows`: writes mean[c], invstd[c] (biased var, eps) and, when
+ * running_mean != NULL, updates running_mean/var with `momentum` (unbiased var), as
+ * nn.BatchNorm does in train(). */
+int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps, float momentum,
+                 float* mean, float* invstd, float* running_mean, float* running_var,
+                 int64_t* num_batches_tracked /* may be NULL; += 1 */,
+                 double* workspace, glf_stream_t s);
+/* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  For eval() pass running_mean and
+ * 1/sqrt(running_var+eps) (glf_bn_eval_coeffs).  In-place (y == x) allowed. */
+int glf_bn_eval_coeffs(const float* running_mean, const float* running_var, float eps,
+                       float* mean, float* invstd, int c, glf_stream_t s);
+int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
+                 const float* mean, const float* invstd, const float* gamma, const float* beta,
+                 int rows, int c, int relu, glf_stream_t s);
+/* Backward.  y is the forward output (ReLU mask = y > 0) and may be NULL when relu == 0.
+ * training != 0: full batch-stat backward; training == 0: dx = dy*mask*gamma*invstd.
+ * dres (may be NULL) receives dy*mask (gradient of the residual input). */
+int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
+               const float* mean, const float* invstd, const float* gamma,
+               float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
+               int rows, int c, int relu, int training, double* workspace, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
+ * Pooling / resampling / pointwise pieces of the path.
+ * ------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(3, stride 2, pad 1) on [N][H][W][C] -> [N][Ho][Wo][C]; idx (uint8, same shape as
+ * y) records the winning tap (first maximum in scan order, as ATen). */
+int glf_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, glf_stream_t s);
+int glf_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, glf_stream_t s);
+/* AdaptiveAvgPool2d(1) (deeplabv3.py:126): x [N][P][C] -> y [N][C], and its backward. */
+int glf_avgpool_fwd(const float* x, float* y, int n, int p, int c, glf_stream_t s);
+/* broadcast rows: y[n][p][0..c) (row stride ldy) = x[n][0..c) -- the "bilinear from 1x1"
+ * upsample of ASPPPooling (deeplabv3.py:135). */
+int glf_bcast_rows_fwd(const float* x, float* y, int ldy, int n, int p, int c, glf_stream_t s);
+/* dx[n][c] = scale * sum_p dy[n][p][c] (row stride lddy): backward of the broadcast (scale=1)
+ * and, with scale = 1/p on a dense dy, nothing else; avgpool backward is bcast with scale 1/p. */
+int glf_sum_rows_fwd(const float* dy, int lddy, float* dx, float scale, int n, int p, int c, glf_stream_t s);
+int glf_bcast_rows_scaled(const float* x, float* y, int ldy, float scale, int n, int p, int c, glf_stream_t s);
+/* Stand-alone nn.ReLU (the fused paths apply it inside glf_bn_apply). */
+int glf_relu_fwd(const float* x, float* y, int64_t numel, glf_stream_t s);
+int glf_relu_bwd(const float* dy, const float* y, float* dx, int64_t numel, glf_stream_t s);
+/* Dropout with a counter-based generator: keep iff hash(seed, element) >= p.  y = x*keep/(1-p). */
+int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, glf_stream_t s);
+/* Local gate (a5, ours.py:1802-1816): a[r] = sigmoid(w * max_c sigmoid(cls[r][c]) * sigmoid(ctr[r])),
+ * y[r][:] = f[r][:] * a[r].  argmax (int32 per row) is saved for backward. */
+int glf_gate_fwd(const float* cls, int ncls, const float* ctr, const float* f, float* y, float* a,
+                 int32_t* argmax, float weight, int rows, int c, glf_stream_t s);
+/* df[r][:] = dy[r][:]*a[r]; dcls/dctr from da[r] = sum_c dy[r][c]*f[r][c]. */
+int glf_gate_bwd(const float* dy, const float* f, const float* cls, int ncls, const float* ctr,
+                 const float* a, const int32_t* argmax, float weight,
+                 float* df, float* dcls, float* dctr, int rows, int c, glf_stream_t s);
+/* Stack / slice views for the fusion block (ours.py:1819-1834): frame-strided row copies.
+ * dst[n][.] (frame stride dst_fs) = src[n][.] (frame stride src_fs), `inner` floats per frame. */
+int glf_copy_frames(const float* src, int64_t src_fs, float* dst, int64_t dst_fs,
+                    int n, int64_t inner, glf_stream_t s);
+/* dst = a + b with independent frame strides (f4_fusion = f4_global_fusion + f4_local_fusion). */
+int glf_add_frames(const float* a, int64_t a_fs, const float* b, int64_t b_fs, float* dst, int64_t dst_fs,
+                   int n, int64_t inner, glf_stream_t s);
+/* W_z tail of TPAVIModule (ours.py:908-915): z = LayerNorm_C( BN(w) + x ) with the BN already
+ * folded into per-channel (bn_mean, bn_invstd, gamma, beta).  Saves row mean / rstd. */
+int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn_mean, const float* bn_invstd,
+                      const float* bn_gamma, const float* bn_beta, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, float* z, float* row_mean, float* row_rstd,
+                      int rows, int c, glf_stream_t s);
+/* LayerNorm backward: du (gradient w.r.t. u = BN(w)+x), dgamma/dbeta of the LayerNorm.
+ * workspace: glf_bn_workspace(rows, c) doubles. */
+int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x, const float* bn_mean,
+                      const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                      const float* ln_gamma, const float* row_mean, const float* row_rstd,
+                      float* du, float* dln_gamma, float* dln_beta, int rows, int c,
+                      double* workspace, glf_stream_t s);
+/* Row softmax in place over `cols` (TPAVI 'embedded' mode, ours.py:896-897) and its backward
+ * ds = p * (dp - sum(dp*p)). */
+int glf_softmax_rows(float* x, int64_t rows, int cols, glf_stream_t s);
+int glf_softmax_rows_bwd(const float* p, float* dp_inout, int64_t rows, int cols, glf_stream_t s);
+/* F.interpolate(mode='bilinear', align_corners=False) (ours.py:1838,1841): x [N][h][w][C]
+ * channels-last -> y [N][C][H][W] (NCHW, what the caller's loss consumes), and its adjoint. */
+int glf_bilinear_up_fwd(const float* x, float* y, int n, int h, int w, int c, int ho, int wo, glf_stream_t s);
+int glf_bilinear_up_bwd(const float* dy, float* dx, int n, int h, int w, int c, int ho, int wo, glf_stream_t s);
+/* nn.BCEWithLogitsLoss(reduction='sum') (main.py:87,209-211): loss_out (double[1], zeroed by the
+ * call) and, when dx != NULL, dx = (sigmoid(x) - t) * grad_scale * (*grad_scale_dev), the latter a
+ * device scalar (autograd's upstream gradient) that may be NULL. */
+int glf_bce_logits_sum(const float* x, const float* t, double* loss_out, float* dx, float grad_scale,
+                       const float* grad_scale_dev, int64_t numel, glf_stream_t s);
+/* Trainer._calculate_overlap_metrics (main.py:800-815) on pred = sigmoid(x) > 0.5:
+ * counts[4] = {tp, fp, fn, tn} as int64 (zeroed by the call). */
+int glf_overlap_counts(const float* logits, const float* target, int64_t* counts, int64_t numel, glf_stream_t s);
+/* bias gradient: db[c] = sum_r dy[r][c]; workspace glf_bn_workspace(rows, c) doubles. */
+int glf_colsum(const float* dy, int lddy, float* db, int rows, int c, double* workspace, glf_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLFUSION_H */

@@ -285,7 +285,8 @@ class Global_and_Local(nn.Module):
         f4_local = {}
         for v in self.view_num:
             # ours.py:1802-1807: AdaptiveMaxPool3d((1,h,w)) on a 4-D tensor == max over the class channels
-            m = torch.sigmoid(self.classifier[v](f4[v])).amax(dim=1, keepdim=True)
+            s = torch.sigmoid(self.classifier[v](f4[v]))
+            m = F.adaptive_max_pool3d(s, (1, s.shape[2], s.shape[3]))   # same op => same tie-breaking in backward
             c = torch.sigmoid(self.centerness[v](f4[v]))                           # ours.py:1809-1811
             a = torch.sigmoid(self.center_aware_weight * m * c)                    # ours.py:1814-1815
             f4_local[v] = f4[v] * a                                                # ours.py:1816

@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads and exports every symbol include/glfusion.h declares; the
+host package imports; the product path refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import glfusion_amd
+from glfusion_amd import _lib
+
+
+def test_header_parses_and_library_exports_every_symbol():
+    protos = _lib.parse_header()
+    text = open(_lib.HEADER).read()
+    declared = set(re.findall(r"\b(glf_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    assert declared == set(protos), declared ^ set(protos)
+    assert len(protos) >= 35
+    assert os.path.exists(_lib.LIB_PATH), "build the engine first: make -C gl-fusion_amd/csrc"
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), f"libglfusion_hip.so does not export {name}"
+    dll.glf_abi_version.restype = ctypes.c_int
+    assert dll.glf_abi_version() == 1
+    # pure host-side queries work without a GPU
+    dll.glf_bn_workspace.restype = ctypes.c_size_t
+    dll.glf_bn_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
+    assert dll.glf_bn_workspace(50176, 2048) == 2 * 1024 * 2048 + 2 * 2048
+
+
+def test_gemm_params_struct_matches_header_layout():
+    # field order / count of the ctypes mirror against the header text
+    text = open(_lib.HEADER).read()
+    body = re.search(r"typedef struct \{(.*?)\} glf_gemm_params;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.split(None, 1)[1]
+        names += [n.strip() for n in parts.split(",")]
+    assert names == [f[0] for f in _lib.GemmParams._fields_]
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    dll.glf_sizeof_gemm_params.restype = ctypes.c_size_t
+    assert ctypes.sizeof(_lib.GemmParams) == dll.glf_sizeof_gemm_params()
+
+
+def test_no_cpu_fallback():
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 1, 1))
+    m = Global_and_Local(["1"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m({"1": torch.zeros(1, 1, 112, 112)})
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gl-fusion_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_tap_masks():
+    from glfusion_amd.ops import tap_mask
+    full = (1 << 9) - 1
+    assert tap_mask(1, 28, 28, 28, 28, 3, 3, 1, 1, 1) == full
+    assert tap_mask(1, 28, 28, 28, 28, 3, 3, 1, 12, 12) == full
+    assert tap_mask(1, 28, 28, 28, 28, 3, 3, 1, 24, 24) == full
+    assert tap_mask(1, 28, 28, 28, 28, 3, 3, 1, 36, 36) == 1 << 4          # rate 36 on 28x28 == centre tap only
+    assert tap_mask(2, 28, 28, 28, 28, 3, 3, 1, 36, 36) == 1 << 4
+    assert tap_mask(1, 28, 28, 55, 55, 3, 3, 2, 1, 1) == full
+    assert tap_mask(2, 55, 55, 28, 28, 3, 3, 2, 1, 1) == full

@@ -1,0 +1,299 @@
+"""GPU: every HIP kernel (through the C ABI, via glfusion_amd.ops) against a plain PyTorch fp32
+CPU reference of the same op on the same seeded inputs.  Tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def close(a, b, tol):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs()
+    ok = bool((err <= tol + tol * b.abs()).all())
+    if not ok:
+        print("max abs err", float(err.max()), "max |ref|", float(b.abs().max()), "tol", tol)
+    return ok
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from glfusion_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,batch", [(300, 70, 52, 1), (128, 128, 32, 1), (517, 260, 100, 3), (64, 5, 256, 1), (1000, 256, 5, 1)])
+def test_gemm_nt_nn_tn_plain(ops, M, N, K, batch):
+    A = rnd(batch, M, K, seed=1)
+    Bnk = rnd(batch, N, K, seed=2)
+    bias = rnd(N, seed=3)
+    a, b, bi = A.to(DEV), Bnk.to(DEV), bias.to(DEV)
+    # NT
+    c = torch.empty(batch, M, N, device=DEV)
+    ops.gemm("nt", a, b, c, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bi, batch=batch, bsa=M * K, bsb=N * K, bsc=M * N, alpha=0.5)
+    ref = 0.5 * torch.matmul(A.double(), Bnk.double().transpose(1, 2)) + bias.double()
+    assert close(c, ref, 5e-5)
+    # accumulate
+    ops.gemm("nt", a, b, c, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch=batch, bsa=M * K, bsb=N * K, bsc=M * N, accumulate=True)
+    assert close(c, ref + torch.matmul(A.double(), Bnk.double().transpose(1, 2)), 5e-5)
+    # NN
+    Bkn = Bnk.transpose(1, 2).contiguous()
+    c2 = torch.empty(batch, M, N, device=DEV)
+    ops.gemm("nn", a, Bkn.to(DEV), c2, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, batch=batch, bsa=M * K, bsb=N * K, bsc=M * N)
+    assert close(c2, torch.matmul(A.double(), Bkn.double()), 5e-5)
+    # TN: C[m][n] = sum_r A2[r][m] * B2[r][n], reduction over the M rows here
+    B2 = rnd(batch, M, N, seed=4)
+    for split in (1, 3):
+        c3 = torch.zeros(batch, K, N, device=DEV)
+        ops.gemm("tn", a, B2.to(DEV), c3, M=K, N=N, K=M, lda=K, ldb=N, ldc=N, batch=batch, bsa=M * K, bsb=M * N, bsc=K * N, split=split)
+        assert close(c3, torch.matmul(A.double().transpose(1, 2), B2.double()), 5e-5)
+
+
+def test_gemm_bad_arguments_raise(ops):
+    a = torch.zeros(4, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="M,N,K"):
+        ops.gemm("nt", a, a, a, M=0, N=4, K=4, lda=4, ldb=4, ldc=4)
+    with pytest.raises(RuntimeError, match="tap_mask"):
+        ops.gemm("nt", a, a, a, M=4, N=4, K=4, lda=4, ldb=4, ldc=4, mask=2)
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONVS = [
+    # n, h, w, cin, cout, k, stride, pad, dil, bias
+    (2, 14, 14, 64, 96, 1, 1, 0, 1, False),
+    (2, 15, 13, 32, 40, 3, 1, 1, 1, False),
+    (2, 55, 55, 16, 24, 3, 2, 1, 1, False),        # layer2.0.conv2 geometry (55 -> 28)
+    (2, 55, 55, 16, 24, 1, 2, 0, 1, False),        # layer2.0.downsample geometry
+    (2, 28, 28, 32, 32, 3, 1, 2, 2, False),
+    (2, 28, 28, 32, 32, 3, 1, 4, 4, False),
+    (2, 28, 28, 64, 32, 3, 1, 12, 12, False),      # ASPP rates on a 28x28 map
+    (2, 28, 28, 64, 32, 3, 1, 24, 24, False),
+    (2, 28, 28, 64, 32, 3, 1, 36, 36, False),      # centre tap only
+    (3, 28, 28, 256, 5, 1, 1, 0, 1, True),         # head output conv (Cout = 5, bias)
+    (3, 28, 28, 256, 1, 1, 1, 0, 1, True),         # centerness output conv (Cout = 1, bias)
+    (1, 1, 1, 64, 32, 1, 1, 0, 1, False),          # ASPP pooled branch (M = N frames)
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_fwd_bwd(ops, cfg):
+    n, h, w, cin, cout, k, stride, pad, dil, has_bias = cfg
+    x = rnd(n, cin, h, w, seed=10).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=11) / np.sqrt(cin * k * k)).requires_grad_(True)
+    b = rnd(cout, seed=12).requires_grad_(True) if has_bias else None
+    y_ref = F.conv2d(x, wt, b, stride=stride, padding=pad, dilation=dil)
+    gy = rnd(*y_ref.shape, seed=13)
+    y_ref.backward(gy)
+
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    wd = wt.detach().to(DEV).requires_grad_(True)
+    bd = b.detach().to(DEV).requires_grad_(True) if has_bias else None
+    y = ops.conv2d(xh, wd, bd, stride, pad, dil)
+    assert tuple(y.shape) == (n, y_ref.shape[2], y_ref.shape[3], cout)
+    assert close(y.permute(0, 3, 1, 2), y_ref, 2e-5)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(xh.grad.permute(0, 3, 1, 2), x.grad, 5e-5)
+    assert close(wd.grad, wt.grad, 1e-4)
+    if has_bias:
+        assert close(bd.grad, b.grad, 1e-4)
+
+
+def test_conv1x1_cat(ops):
+    xs = [rnd(2, 7, 9, 32, seed=20 + i) for i in range(3)]
+    wt = rnd(24, 96, 1, 1, seed=29) / 10
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    wr = wt.clone().requires_grad_(True)
+    ref = F.conv2d(torch.cat([t.permute(0, 3, 1, 2) for t in xr], 1), wr)
+    gy = rnd(*ref.shape, seed=30)
+    ref.backward(gy)
+    xd = [t.to(DEV).requires_grad_(True) for t in xs]
+    wd = wt.to(DEV).requires_grad_(True)
+    y = ops.conv1x1_cat(wd, xd)
+    assert close(y.permute(0, 3, 1, 2), ref, 2e-5)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    for a, b in zip(xd, xr):
+        assert close(a.grad, b.grad, 5e-5)
+    assert close(wd.grad, wr.grad, 1e-4)
+
+
+def test_stem(ops):
+    x = rnd(3, 1, 40, 37, seed=40, lo=0.0)
+    wt = (rnd(64, 1, 7, 7, seed=41) / 7).requires_grad_(True)
+    b = rnd(64, seed=42).requires_grad_(True)
+    ref = F.conv2d(x, wt, b, stride=1, padding=2)
+    gy = rnd(*ref.shape, seed=43)
+    ref.backward(gy)
+    wd, bd = wt.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = ops.stem7x7(x.permute(0, 2, 3, 1).contiguous().to(DEV), wd, bd, 2)
+    assert close(y.permute(0, 3, 1, 2), ref, 1e-5)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(wd.grad, wt.grad, 1e-4)
+    assert close(bd.grad, b.grad, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ norm
+@pytest.mark.parametrize("training,relu,res", [(True, True, False), (True, True, True), (True, False, False), (False, True, True), (False, False, False)])
+@pytest.mark.parametrize("shape", [(3, 9, 11, 64), (2, 5, 5, 2048), (4, 1, 1, 256)])
+def test_batch_norm_act(ops, training, relu, res, shape):
+    c = shape[-1]
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(c, seed=50, lo=0.5, hi=1.5)); bn.bias.copy_(rnd(c, seed=51))
+        bn.running_mean.copy_(rnd(c, seed=52) * 0.1); bn.running_var.copy_(rnd(c, seed=53, lo=0.5, hi=1.5))
+    bn.train(training)
+    import copy
+    bd = copy.deepcopy(bn).to(DEV)
+    x = (rnd(*shape, seed=54) * 2 + 0.3)
+    r = rnd(*shape, seed=55) if res else None
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    ref = bn(xr.permute(0, 3, 1, 2))
+    if res:
+        ref = ref + rr.permute(0, 3, 1, 2)
+    if relu:
+        ref = F.relu(ref)
+    gy = rnd(*ref.shape, seed=56)
+    ref.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    rd = r.to(DEV).requires_grad_(True) if res else None
+    y = ops.batch_norm_act(xd, bd, relu, rd)
+    assert close(y.permute(0, 3, 1, 2), ref, 2e-5)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(xd.grad, xr.grad, 1e-4)
+    assert close(bd.weight.grad, bn.weight.grad, 2e-4)
+    assert close(bd.bias.grad, bn.bias.grad, 2e-4)
+    if res:
+        assert close(rd.grad, rr.grad, 1e-5)
+    assert close(bd.running_mean, bn.running_mean, 1e-6)
+    assert close(bd.running_var, bn.running_var, 1e-5)
+    assert int(bd.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+def test_relu_dropout_maxpool_avgpool(ops):
+    x = rnd(2, 13, 11, 64, seed=60)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.relu(xd)
+    assert close(y, F.relu(x), 0)
+    # maxpool on post-ReLU data (many exact ties at 0): values AND gradient routing must match ATen
+    xr = F.relu(x).clone().requires_grad_(True)
+    ref = F.max_pool2d(xr.permute(0, 3, 1, 2), 3, 2, 1)
+    gy = rnd(*ref.shape, seed=61)
+    ref.backward(gy)
+    xm = F.relu(x).to(DEV).requires_grad_(True)
+    ym = ops.maxpool3x3s2(xm)
+    assert close(ym.permute(0, 3, 1, 2), ref, 0)
+    ym.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(xm.grad, xr.grad, 1e-6)
+    # avgpool + broadcast
+    xa = x.clone().requires_grad_(True)
+    ra = F.adaptive_avg_pool2d(xa.permute(0, 3, 1, 2), 1)
+    rb = F.interpolate(ra, size=(13, 11), mode="bilinear", align_corners=False)
+    gb = rnd(*rb.shape, seed=62)
+    rb.backward(gb)
+    xg = x.to(DEV).requires_grad_(True)
+    p = ops.global_avgpool(xg)
+    assert close(p.permute(0, 3, 1, 2), ra, 1e-6)
+    bb = ops.broadcast_hw(p, 13, 11)
+    assert close(bb.permute(0, 3, 1, 2), rb, 1e-6)
+    bb.backward(gb.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(xg.grad, xa.grad, 1e-6)
+    # dropout: p = 0.5 keeps ~half, scales by 2, backward uses the same mask
+    big = torch.ones(64, 64, 64, device=DEV, requires_grad=True)
+    d = ops.dropout(big, 0.5, True)
+    keep = (d != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    assert set(torch.unique(d.detach()).cpu().tolist()) == {0.0, 2.0}
+    d.sum().backward()
+    assert torch.equal(big.grad, d.detach())
+    assert ops.dropout(big, 0.5, False) is big and ops.dropout(big, 0.0, True) is big
+
+
+def test_local_gate(ops):
+    n, h, w, c = 2, 6, 5, 128
+    cls, ctr, f = rnd(n, h, w, 5, seed=70) * 3, rnd(n, h, w, 1, seed=71) * 3, rnd(n, h, w, c, seed=72)
+    cr, tr, fr = cls.clone().requires_grad_(True), ctr.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    s = torch.sigmoid(cr.permute(0, 3, 1, 2))
+    m = F.adaptive_max_pool3d(s, (1, h, w))                       # the reference's op (ours.py:1805-1807)
+    a = torch.sigmoid(20 * m * torch.sigmoid(tr.permute(0, 3, 1, 2)))
+    ref = fr.permute(0, 3, 1, 2) * a
+    gy = rnd(*ref.shape, seed=73)
+    ref.backward(gy)
+    cd, td, fd = cls.to(DEV).requires_grad_(True), ctr.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+    y = ops.local_gate(cd, td, fd, 20)
+    assert close(y.permute(0, 3, 1, 2), ref, 1e-5)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert close(fd.grad, fr.grad, 1e-5)
+    assert close(cd.grad, cr.grad, 1e-4)
+    assert close(td.grad, tr.grad, 1e-4)
+
+
+def test_stack_and_add_views(ops):
+    xs = [rnd(2, 4, 3, 8, seed=80 + i) for i in range(3)]
+    xd = [t.to(DEV).requires_grad_(True) for t in xs]
+    st = ops.stack_views(xd)
+    assert close(st, torch.stack(xs, 1), 0)
+    g, l = rnd(2, 3, 4, 3, 8, seed=85), rnd(2, 3, 4, 3, 8, seed=86)
+    gd, ld = g.to(DEV).requires_grad_(True), l.to(DEV).requires_grad_(True)
+    outs = ops.add_views(gd, ld)
+    for i in range(3):
+        assert close(outs[i], g[:, i] + l[:, i], 0)
+    gy = [rnd(2, 4, 3, 8, seed=87 + i) for i in range(3)]
+    (outs[0] * gy[0].to(DEV)).sum().backward(retain_graph=True)       # only one view used: others get zeros
+    assert close(gd.grad[:, 0], gy[0], 0) and float(gd.grad[:, 1:].abs().max()) == 0.0
+    (st * torch.stack(gy, 1).to(DEV)).sum().backward()
+    for i in range(3):
+        assert close(xd[i].grad, gy[i], 0)
+
+
+@pytest.mark.parametrize("h,w,ho,wo", [(28, 28, 112, 112), (7, 5, 28, 20), (56, 56, 224, 224)])
+def test_bilinear_up(ops, h, w, ho, wo):
+    x = rnd(2, h, w, 5, seed=90)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr.permute(0, 3, 1, 2), size=(ho, wo), mode="bilinear", align_corners=False)
+    gy = rnd(*ref.shape, seed=91)
+    ref.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.bilinear_up(xd, ho, wo)
+    assert y.is_contiguous() and tuple(y.shape) == (2, 5, ho, wo)
+    assert close(y, ref, 1e-6)
+    y.backward(gy.to(DEV))
+    assert close(xd.grad, xr.grad, 1e-5)
+
+
+def test_bce_and_overlap(ops):
+    x = rnd(3, 5, 40, 40, seed=100) * 6
+    t = (rnd(3, 5, 40, 40, seed=101) > 0.4).float()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.BCEWithLogitsLoss(reduction="sum")(xr, t)
+    (ref * 0.7).backward()
+    xd = x.to(DEV).requires_grad_(True)
+    loss = ops.bce_with_logits_sum(xd, t.to(DEV))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    (loss * 0.7).backward()
+    assert close(xd.grad, xr.grad, 1e-6)
+    counts = ops.overlap_counts(xd.detach(), t.to(DEV)).cpu()
+    pred = torch.where(torch.sigmoid(x) > 0.5, 1, 0)
+    tp = int((pred * t).sum()); fp = int((pred * (1 - t)).sum()); fn = int(((1 - pred) * t).sum()); tn = int(((1 - pred) * (1 - t)).sum())
+    assert counts.tolist() == [tp, fp, fn, tn]                        # integer work: bit-exact
+    from oracle import glfusion_ref as orc
+    want = [float(v) for v in orc.overlap_metrics(t, pred)]
+    got = ops.overlap_metrics_from_counts(counts)
+    assert np.allclose(got, want, atol=1e-6, rtol=0)
+
+
+def test_softmax_rows(ops):
+    x = rnd(37, 301, seed=110) * 5
+    xd = x.to(DEV).clone()
+    from glfusion_amd._lib import lib, check
+    check(lib.glf_softmax_rows(ops._p(xd), 37, 301, ops._stream()))
+    assert close(xd, torch.softmax(x, -1), 1e-6)
