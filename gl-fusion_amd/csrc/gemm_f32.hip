@@ -81,19 +81,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// 64x64 per wave, K = 32 from LDS tiles laid out [k][m] / [k][n]
+// 64x64 per wave, K = 32 from LDS tiles laid out [k][m] / [k][n].
+// Two-level accumulation: the 32-deep K-tile is summed by the MFMA chain into fresh accumulators
+// (C = 0 inline constant), which are then added to the running sums on the VALU (hidden under the
+// next MFMAs).  A single f32 fma chain over K = 9*2048 products has a ~sqrt(K) rounding walk;
+// chains of 32 + K/32 keep the contraction at the accuracy of a blocked CPU GEMM.
 template <int LDA, int LDB>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ a_s, const float* __restrict__ b_s,
                                           f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
+    f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};
 #pragma unroll
     for (int k = 0; k < BK; k += 2) {
         const float a0 = a_s[k * LDA], a1 = a_s[k * LDA + 32];
         const float b0 = b_s[k * LDB], b1 = b_s[k * LDB + 32];
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+        t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, t00, 0, 0, 0);
+        t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, t01, 0, 0, 0);
+        t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, t10, 0, 0, 0);
+        t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, t11, 0, 0, 0);
     }
+    c00 += t00; c01 += t01; c10 += t10; c11 += t11;
 }
 
 __device__ __forceinline__ void scatter4(float* dst, int ld, const float4& v) {

@@ -11,6 +11,7 @@ tensors (== the row-major matrix [N*H*W, C] the kernels see).
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -150,7 +151,9 @@ def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
     return db
 
 
-# weight re-layout cache: OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes
+# weight re-layout cache: OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes.
+# Entries are validated by object identity through a weak reference (id() and data_ptr() of a freed
+# parameter can both be reused by a new one) plus the in-place version counter.
 _wt_cache = {}
 
 
@@ -160,11 +163,11 @@ def tap_major(weight: torch.Tensor) -> torch.Tensor:
         return _contig(weight.detach()).view(1, co, ci)
     key = id(weight)
     hit = _wt_cache.get(key)
-    if hit is not None and hit[0] == weight._version and hit[2] == weight.data_ptr() and hit[1].shape == (kh * kw, co, ci):
-        return hit[1]
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[3] == weight.data_ptr():
+        return hit[2]
     wt = torch.empty(kh * kw, co, ci, dtype=torch.float32, device=weight.device)
     check(lib.glf_oihw_to_tap_major(_p(_contig(weight.detach())), _p(wt), co, ci, kh * kw, _stream()), "oihw_to_tap_major")
-    _wt_cache[key] = (weight._version, wt, weight.data_ptr())
+    _wt_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wt_cache.pop(k, None)), weight._version, wt, weight.data_ptr())
     return wt
 
 

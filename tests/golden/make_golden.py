@@ -74,13 +74,15 @@ def grads_summary(model: torch.nn.Module):
 
 
 def main() -> None:
+    only = set(sys.argv[1:])          # optional: tpavi head eval train
+    want = lambda name: not only or name in only
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     ours, dl = import_reference()
     out = {}
 
     # ------------------------------------------------------------------ unit: TPAVIModule
-    for mode in ("dot", "embedded"):
+    for mode in (("dot", "embedded") if want("tpavi") else ()):
         m = ours.TPAVIModule(in_channels=64, mode=mode)
         orc.closed_form_fill(m, salt=3)
         m.train()
@@ -99,10 +101,12 @@ def main() -> None:
         print("tpavi", mode, "|z|max", float(z.abs().max()))
 
     # ------------------------------------------------------------------ unit: DeepLabHead
+    if not want("head"):
+        head = None
     head = dl.DeepLabHead(64, 5)
     orc.closed_form_fill(head, salt=5)
     orc.set_dropout(head, 0.0)
-    x = orc.closed_form_tensor((2, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)
+    x = orc.closed_form_tensor((4, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)   # N=4: the pooled-branch BN needs > 2 samples
     head.train()
     y = head(x)
     w = orc.closed_form_tensor(tuple(y.shape), 202, -1.0, 1.0)
@@ -120,7 +124,7 @@ def main() -> None:
     print("head |y|max", float(y.abs().max()))
 
     # ------------------------------------------------------------------ e2e eval, config-2 views, N=2
-    for tag, views, n in (("c2", ["1", "3", "4"], 2), ("c1", ["1"], 8)):
+    for tag, views, n in ((("c2", ["1", "3", "4"], 2), ("c1", ["1"], 8)) if want("eval") else ()):
         model = ours.Global_and_Local(view_num=views)
         keys = list(model.state_dict().keys())
         orc.closed_form_fill(model, salt=1)
@@ -154,7 +158,9 @@ def main() -> None:
                     fh.write(f"{k} {tuple(model.state_dict()[k].shape)}\n")
 
     # ------------------------------------------------------------------ train-mode step, dropout p = 0
-    views, n = ["1", "3", "4"], 2
+    if not want("train"):
+        return
+    views, n = ["1", "3", "4"], 4          # N=4: train-mode BN over 2 pooled samples is degenerate (output +-1, zero gradient)
     model = ours.Global_and_Local(view_num=views)
     orc.closed_form_fill(model, salt=1)
     orc.set_dropout(model, 0.0)
@@ -178,6 +184,8 @@ def main() -> None:
     l64.backward()
     _, norms64, samples64 = grads_summary(m64)
     d["loss64"] = np.array(float(l64))
+    for v in views:
+        d[f"mask64:{v}"] = t2n(p64[v].float())
     d["grad_norms64"] = norms64
     d.update({"g64:" + k: v for k, v in samples64.items()})
     del m64, p64, l64

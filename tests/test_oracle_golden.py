@@ -46,7 +46,7 @@ def test_deeplab_head_unit(golden_dir):
     head = orc.DeepLabHead(64, 5)
     orc.closed_form_fill(head, salt=5)
     orc.set_dropout(head, 0.0)
-    x = orc.closed_form_tensor((2, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)
+    x = orc.closed_form_tensor((4, 64, 28, 28), 201, 0.0, 1.0).requires_grad_(True)
     head.train()
     y = head(x)
     w = orc.closed_form_tensor(tuple(y.shape), 202, -1.0, 1.0)
@@ -98,7 +98,7 @@ def test_e2e_eval(golden_dir, tag, views, n):
 
 def test_e2e_train_step(golden_dir):
     g = np.load(os.path.join(golden_dir, "e2e_train_step.npz"))
-    views, n = ["1", "3", "4"], 2
+    views, n = ["1", "3", "4"], 4
     model = orc.Global_and_Local(views)
     orc.closed_form_fill(model, salt=1)
     orc.set_dropout(model, 0.0)
