@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec forward+backward of GL-Fusion's hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): (B, V, T, H, W) = (4, 3, 16, 112, 112)
+per GPU, fp32, views ['1','3','4'] => N = B*T = 64 frames per view per rank; weak scaling (the per-GPU
+batch is fixed as N grows).  One step = forward -> sum_v BCEWithLogits(sum) -> backward through the HIP
+engine (optimizer step excluded, gradient all-reduce included when N > 1), train() mode, Dropout active.
+Synthetic data: images U[0,1), targets Bernoulli(0.3), generated on device (seed 1234 + rank); weights
+default-init under torch.manual_seed(0) with the W_z BatchNorm gamma re-drawn N(1, 0.1) so the attention
+branch is live.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : dominant kernel's dense algorithmic FLOP/s (HIP events on the launch stream, timed region)
+                 vs the 157.3 TF fp32 MFMA peak
+  cpu_baseline : the oracle (CPU restatement) timed on the host cores on a bounded sample (N=1 run only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+VIEWS = ["1", "3", "4"]
+B, T, H, W = 4, 16, 112, 112
+FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+DENSE_GFLOP_PER_FRAME_FWD = 531.57      # 2 x 265.786 GMAC, all 3 views, per frame
+
+
+def build_model(dev):
+    from glfusion_amd.models import Global_and_Local
+    torch.manual_seed(0)
+    model = Global_and_Local(VIEWS)
+    with torch.no_grad():
+        for attn in (model.global_attn, model.local_attn):
+            attn.W_z[1].weight.normal_(1.0, 0.1)
+    return model.to(dev).train()
+
+
+def make_batch(dev, rank, n_frames):
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = {v: torch.rand(n_frames, 1, H, W, device=dev, generator=g) for v in VIEWS}
+    tgts = {v: (torch.rand(n_frames, 5, H, W, device=dev, generator=g) < 0.3).float() for v in VIEWS}
+    return imgs, tgts
+
+
+def cpu_baseline(frames_per_view: int = 2, steps: int = 1):
+    """The oracle's forward+backward on the host cores, same shapes per frame, a bounded sample."""
+    from oracle import glfusion_ref as orc
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = orc.Global_and_Local(VIEWS)
+    with torch.no_grad():
+        for attn in (model.global_attn, model.local_attn):
+            attn.W_z[1].weight.normal_(1.0, 0.1)
+    model.train()
+    g = torch.Generator().manual_seed(1234)
+    imgs = {v: torch.rand(frames_per_view, 1, H, W, generator=g) for v in VIEWS}
+    tgts = {v: (torch.rand(frames_per_view, 5, H, W, generator=g) < 0.3).float() for v in VIEWS}
+    orc.train_step(model, imgs, tgts)                     # warm-up (allocations, oneDNN primitives)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.train_step(model, imgs, tgts)
+    dt = (time.perf_counter() - t0) / steps
+    clips = frames_per_view / T                           # 1 clip = V views x T frames
+    return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) fwd+bwd, 3 views x {frames_per_view} frames x 112x112, "
+                      f"{steps} timed step(s) after 1 warm-up, {dt:.2f} s/step, scaled per frame to a 16-frame clip"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from glfusion_amd import ops
+    from glfusion_amd.ddp import GradAllReducer
+
+    n_frames = args.clips * T
+    model = build_model(dev)
+    reducer = GradAllReducer(model)
+    reducer.broadcast_parameters(0)
+    imgs, tgts = make_batch(dev, rank, n_frames)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        pred = model(imgs)[0]
+        loss = None
+        for v in VIEWS:
+            l = ops.bce_with_logits_sum(pred[v], tgts[v])
+            loss = l if loss is None else loss + l
+        loss.backward()
+        reducer.finalize()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof = []
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    loss_val = float(loss)
+    if not (loss_val == loss_val and abs(loss_val) != float("inf")):
+        raise SystemExit(f"non-finite loss {loss_val}")
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        clips_total = args.clips * world * args.steps
+        value = clips_total / dt
+        # ---- roofline of the dominant contraction kernel (HIP events recorded around every launch) -------
+        agg = {}
+        for name, dense, kept, e0, e1 in prof:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += dense
+            a[2] += kept
+            a[3] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (secs, dense, kept, launches) = dom
+        achieved = dense / secs / 1e12
+        all_secs = sum(a[0] for a in agg.values())
+        all_dense = sum(a[1] for a in agg.values())
+        roofline = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": launches // args.steps, "avg_launch_ms": round(secs / launches * 1e3, 4),
+            "executed_tflops": round(kept / secs / 1e12, 2),
+            "all_contractions": {"achieved": round(all_dense / all_secs / 1e12, 2), "share_of_step": round(all_secs / dt, 4),
+                                 "per_kernel_s_per_step": {k: round(a[0] / args.steps, 4) for k, a in sorted(agg.items())}},
+            "whole_step_dense": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
+        }
+        out = {
+            "metric": "clips/sec fwd+bwd (B=4, 3 views x16x112x112) per GPU, weak scaling", "value": round(value, 4),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
+                       "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames,
+                       "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
+            "loss": loss_val, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

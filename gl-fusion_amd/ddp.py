@@ -1,0 +1,135 @@
+"""Multi-GPU data parallelism for the hot path: one process per GPU, clips (frames) sharded
+across ranks, ONE exchange step per iteration -- an all-reduce of the parameter gradients
+(RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" on CPU for tests).
+
+Replaces the reference's single-process nn.DataParallel (main.py:155), which re-broadcasts
+897 MB of parameters every forward and reduces gradients onto GPU 0.  Semantics kept:
+  * the caller's loss is a SUM over samples (BCEWithLogitsLoss(reduction='sum'), main.py:87),
+    so gradients are SUMMED over ranks (average=False) -- identical to DataParallel's
+    reduce-add of replica gradients for a batch split across devices;
+  * BatchNorm statistics stay per-rank (DataParallel replicas use local statistics too; the
+    reference has no SyncBN).
+Gradients are packed into flat buckets in reverse registration order (~ backward order); a
+bucket is all-reduced asynchronously as soon as its last gradient has been accumulated, so
+communication overlaps the rest of backward.  Parameters that never receive gradients on
+this path (the dead `network.*` template and `*.align_channel.*`) are excluded up front.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def default_ignore(name: str) -> bool:
+    return name.startswith("network.") or ".align_channel." in name or name.startswith("align_channel.")
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        p0 = params[0]
+        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self.offsets = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class GradAllReducer:
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, average: bool = False,
+                 ignore: Optional[Callable[[str], bool]] = default_ignore, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and not (ignore and ignore(n))]
+        self.names = [n for n, _ in named]
+        cap = int(bucket_mb * 1024 * 1024)
+        self.buckets: List[_Bucket] = []
+        cur, size = [], 0
+        for _, p in reversed(named):
+            nbytes = p.numel() * p.element_size()
+            if cur and size + nbytes > cap:
+                self.buckets.append(_Bucket(cur))
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._where = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._where[p] = (b, i)
+        self._handles = []
+        if self.world > 1:
+            for p in self._where:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    # -- one-off: make every rank start from rank 0's parameters and buffers ----------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src, group=self.group)
+
+    def _launch(self, b: _Bucket) -> None:
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _hook(self, p: torch.nn.Parameter) -> None:
+        b, i = self._where[p]
+        off = b.offsets[i]
+        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finalize(self) -> None:
+        """Call once after backward(): launches buckets that did not fill (unused parameters contribute
+        zeros), waits for the collectives and re-points every .grad at its reduced bucket slice."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b.work is None:
+                for i, p in enumerate(b.params):           # parameters whose hook never fired this step
+                    if p.grad is None:
+                        off = b.offsets[i]
+                        b.flat[off:off + p.numel()].zero_()
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            if self.average:
+                b.flat.div_(self.world)
+            for i, p in enumerate(b.params):
+                off = b.offsets[i]
+                p.grad = b.flat[off:off + p.numel()].view_as(p)
+            b.pending = len(b.params)
+            b.work = None
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def shard_frames(n_total: int, rank: int, world: int):
+    """[start, end) of the frames (clips x T) this rank owns: contiguous, equal shares (weak scaling keeps
+    the per-rank share fixed; cross-view attention couples the V views of one frame, so all views of a
+    frame stay on one rank)."""
+    if n_total % world != 0:
+        raise ValueError(f"{n_total} frames do not split evenly over {world} ranks")
+    per = n_total // world
+    return rank * per, (rank + 1) * per
+
+
+def all_reduce_counts(counts: torch.Tensor, process_group=None) -> torch.Tensor:
+    """Sum the 4 overlap counters (tp, fp, fn, tn) over ranks for a global Dice in eval."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=process_group)
+    return counts

@@ -103,6 +103,13 @@ def tap_mask(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, 
     return m
 
 
+# bench.py sets this to a list to time every contraction launch with HIP events on the launch stream
+PROFILER = None
+KERNEL_NAMES = {("nt", False): "gemm_rows_kernel<0,false>", ("nt", True): "gemm_rows_kernel<0,true>",
+                ("nn", False): "gemm_rows_kernel<1,false>", ("nn", True): "gemm_rows_kernel<1,true>",
+                ("tn", False): "gemm_tn_kernel<false>", ("tn", True): "gemm_tn_kernel<true>"}
+
+
 def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: int, N: int, K: int,
          lda: int, ldb: int, ldc: int, bias: Optional[torch.Tensor] = None, taps: int = 1, mask: int = 1,
          tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
@@ -118,6 +125,10 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
     p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
     p.alpha, p.accumulate, p.split = alpha, int(accumulate), split
+    prof = PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     if mode == "nt":
         check(lib.glf_gemm_nt(_p(A), _p(B), _p(bias), _p(Cm), C.byref(p), _stream()), "gemm_nt")
     elif mode == "nn":
@@ -126,6 +137,13 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         check(lib.glf_gemm_tn(_p(A), _p(B), _p(Cm), C.byref(p), _stream()), "gemm_tn")
     else:
         raise ValueError(mode)
+    if prof is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        # dense, reference-equivalent FLOPs of this launch (every tap, padding included) and the FLOPs of the
+        # taps the host-side mask keeps
+        dense = 2.0 * M * N * K * taps * batch
+        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * bin(mask).count("1") / taps, ev0, ev1))
 
 
 def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:

@@ -1,0 +1,98 @@
+"""CPU, world_size 2, gloo: the gradient all-reduce wrapper (glfusion_amd.ddp) produces on every rank
+the gradient of the SUM loss over the global batch, identical parameters stay identical, unused
+parameters are tolerated, and the frame sharding is disjoint and complete."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import glfusion_ref as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Tiny(torch.nn.Module):
+    """Same ingredients as the path at toy size (conv/BN/TPAVI + a dead `network` template)."""
+
+    def __init__(self):
+        super().__init__()
+        self.network = torch.nn.Linear(4, 4)                 # never used: no gradient
+        self.stem = torch.nn.Conv2d(1, 8, 3, padding=1)
+        self.bn = torch.nn.BatchNorm2d(8)
+        self.attn = orc.TPAVIModule(8, mode="dot")
+        self.head = torch.nn.Conv2d(8, 5, 1)
+
+    def forward(self, x):
+        f = torch.relu(self.bn(self.stem(x)))
+        z, _ = self.attn(torch.stack([f, f * 0.5], dim=2))
+        return self.head(z[:, :, 0] + z[:, :, 1])
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from glfusion_amd.ddp import GradAllReducer, shard_frames, all_reduce_counts
+    torch.manual_seed(1234 + rank)                            # different init per rank on purpose
+    model = _Tiny()
+    red = GradAllReducer(model, bucket_mb=0.0002)              # tiny buckets => several collectives in flight
+    assert len(red.buckets) > 2
+    assert all(not n.startswith("network.") and "align_channel" not in n for n in red.names)
+    red.broadcast_parameters(0)
+    n_total = 8
+    xs = orc.closed_form_tensor((n_total, 1, 12, 12), 5)
+    ts = (orc.closed_form_tensor((n_total, 5, 12, 12), 6) < 0.3).float()
+    lo, hi = shard_frames(n_total, rank, world)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="sum")
+    model.eval()                                              # eval BN => per-sample independence => exact check
+    loss = bce(model(xs[lo:hi]), ts[lo:hi])
+    loss.backward()
+    red.finalize()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    counts = all_reduce_counts(torch.tensor([rank + 1, 2, 3, 4]))
+    torch.save({"grads": grads, "state": model.state_dict(), "range": (lo, hi), "counts": counts}, os.path.join(tmp, f"r{rank}.pt"))
+    if rank == 0:                                             # single-process truth on the whole batch
+        ref = _Tiny()
+        ref.load_state_dict(model.state_dict())
+        ref.eval()
+        bce(ref(xs), ts).backward()
+        torch.save({n: p.grad for n, p in ref.named_parameters() if p.grad is not None}, os.path.join(tmp, "truth.pt"))
+    # second step: hooks re-arm, grads keep matching across ranks
+    for p in model.parameters():
+        p.grad = None
+    bce(model(xs[lo:hi]), ts[lo:hi]).backward()
+    red.finalize()
+    torch.save({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, os.path.join(tmp, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(world)]
+    truth = torch.load(tmp_path / "truth.pt")
+    assert r[0]["range"] == (0, 4) and r[1]["range"] == (4, 8)
+    assert r[0]["counts"].tolist() == [3, 4, 6, 8]
+    for k in r[0]["state"]:
+        assert torch.equal(r[0]["state"][k], r[1]["state"][k]), k           # broadcast made replicas identical
+    assert set(r[0]["grads"]) == set(truth) and not any(n.startswith("network.") for n in truth)
+    for n, g in truth.items():
+        assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n            # all ranks hold the same reduced gradient
+        assert torch.allclose(r[0]["grads"][n], g, rtol=1e-4, atol=1e-5), n  # == gradient of the global SUM loss
+    s = [torch.load(tmp_path / f"s{i}.pt") for i in range(world)]
+    for n in truth:
+        assert torch.equal(s[0][n], s[1][n]) and torch.allclose(s[0][n], r[0]["grads"][n], rtol=1e-5, atol=1e-6), n
+
+
+def test_shard_frames_errors():
+    from glfusion_amd.ddp import shard_frames
+    with pytest.raises(ValueError):
+        shard_frames(10, 0, 4)
+    assert [shard_frames(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
