@@ -54,12 +54,25 @@ def make_batch(dev, rank, n_frames):
     return imgs, tgts
 
 
-def cpu_baseline(frames_per_view: int = 2, steps: int = 1):
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(frames_per_view: int = 4, steps: int = 2):
     """The oracle's forward+backward on the host cores, same shapes per frame, a bounded sample."""
     from oracle import glfusion_ref as orc
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle on {cores} host threads ...", file=sys.stderr, flush=True)
     model = orc.Global_and_Local(VIEWS)
     with torch.no_grad():
         for attn in (model.global_attn, model.local_attn):
@@ -69,6 +82,7 @@ def cpu_baseline(frames_per_view: int = 2, steps: int = 1):
     imgs = {v: torch.rand(frames_per_view, 1, H, W, generator=g) for v in VIEWS}
     tgts = {v: (torch.rand(frames_per_view, 5, H, W, generator=g) < 0.3).float() for v in VIEWS}
     orc.train_step(model, imgs, tgts)                     # warm-up (allocations, oneDNN primitives)
+    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         orc.train_step(model, imgs, tgts)
