@@ -167,7 +167,18 @@ def main():
         value = clips_total / dt
         # ---- roofline of the dominant contraction kernel (HIP events recorded around every launch) -------
         agg = {}
-        for name, dense, kept, e0, e1 in prof:
+        dump = os.environ.get("GLF_BENCH_DUMP")
+        if dump:
+            shapes = {}
+            for name, dense, kept, e0, e1, shp in prof:
+                r = shapes.setdefault((name,) + shp, [0, 0.0, dense, kept])
+                r[0] += 1
+                r[1] += e0.elapsed_time(e1)
+            with open(dump, "w") as fh:
+                fh.write("kernel,M,N,K,taps,kept_taps,batch,split,pad,dil,launches,total_ms,avg_ms,dense_TF,executed_TF\n")
+                for key, (cnt, ms, dense, kept) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(",".join(str(x) for x in key) + f",{cnt},{ms:.3f},{ms / cnt:.4f},{dense * cnt / ms / 1e9:.1f},{kept * cnt / ms / 1e9:.1f}\n")
+        for name, dense, kept, e0, e1, _shp in prof:
             a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += dense

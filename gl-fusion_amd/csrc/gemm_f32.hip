@@ -19,6 +19,9 @@
 //   gemm_rows_kernel<1>  A[m][k] (gathered rows) x B[k][n]   -> conv dgrad, y = theta @ M
 //   gemm_tn_kernel       sum_r A[r][m] * B[src(r)][n]        -> conv wgrad, M = phi^T g
 #include "glf_common.h"
+#ifndef GLF_EXP
+#define GLF_EXP 0
+#endif
 
 namespace {
 
@@ -45,25 +48,31 @@ struct GemmArgs {
     int vec_a, vec_b;
 };
 
+// Scalar copy of the conv geometry: kernels keep it (and every other GemmArgs field they use) in local
+// scalars -- lambdas that capture the by-value kernel argument struct by reference made hipcc spill the whole
+// struct to scratch and re-load fields from there (3x slower).
+struct GeoS { int hs, ws, hd, wd, kw, stride, pad, dil; };
+
 // source row of GEMM row (n,y,x) for `tap`, or -1 when the tap falls into the padding
-__device__ __forceinline__ int map_src(const Geo& g, int gather, int n, int y, int x, int tap) {
-    const int ky = tap / g.kw, kx = tap - ky * g.kw;
+__device__ __forceinline__ int map_src(const int hs, const int ws, const int kw, const int stride, const int pad,
+                                       const int dil, const int gather, int n, int y, int x, int tap) {
+    const int ky = tap / kw, kx = tap - ky * kw;
     int sy, sx;
     if (gather == 1) {
-        sy = y * g.stride - g.pad + ky * g.dil;
-        sx = x * g.stride - g.pad + kx * g.dil;
-        if ((unsigned)sy >= (unsigned)g.hs || (unsigned)sx >= (unsigned)g.ws) return -1;
+        sy = y * stride - pad + ky * dil;
+        sx = x * stride - pad + kx * dil;
+        if ((unsigned)sy >= (unsigned)hs || (unsigned)sx >= (unsigned)ws) return -1;
     } else {
-        sy = y + g.pad - ky * g.dil;
-        sx = x + g.pad - kx * g.dil;
+        sy = y + pad - ky * dil;
+        sx = x + pad - kx * dil;
         if (sy < 0 || sx < 0) return -1;
-        if (g.stride > 1) {
-            if ((sy % g.stride) != 0 || (sx % g.stride) != 0) return -1;
-            sy /= g.stride; sx /= g.stride;
+        if (stride > 1) {
+            if ((sy % stride) != 0 || (sx % stride) != 0) return -1;
+            sy /= stride; sx /= stride;
         }
-        if (sy >= g.hs || sx >= g.ws) return -1;
+        if (sy >= hs || sx >= ws) return -1;
     }
-    return (n * g.hs + sy) * g.ws + sx;
+    return (n * hs + sy) * ws + sx;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
@@ -76,31 +85,67 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
     return v;
 }
 
+// value select (a `cond ? reg4 : make_float4(0.f, 0.f, 0.f, 0.f)` on two lvalues becomes a pointer select through scratch)
+__device__ __forceinline__ float4 keep_if(bool c, const float4 v) {
+    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 // 64x64 per wave, K = 32 from LDS tiles laid out [k][m] / [k][n].
-// Two-level accumulation: the 32-deep K-tile is summed by the MFMA chain into fresh accumulators
-// (C = 0 inline constant), which are then added to the running sums on the VALU (hidden under the
-// next MFMAs).  A single f32 fma chain over K = 9*2048 products has a ~sqrt(K) rounding walk;
-// chains of 32 + K/32 keep the contraction at the accuracy of a blocked CPU GEMM.
-template <int LDA, int LDB>
-__device__ __forceinline__ void mma_ktile(const float* __restrict__ a_s, const float* __restrict__ b_s,
-                                          f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
-    f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};
-#pragma unroll
-    for (int k = 0; k < BK; k += 2) {
-        const float a0 = a_s[k * LDA], a1 = a_s[k * LDA + 32];
-        const float b0 = b_s[k * LDB], b1 = b_s[k * LDB + 32];
-        t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, t00, 0, 0, 0);
-        t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, t01, 0, 0, 0);
-        t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, t10, 0, 0, 0);
-        t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, t11, 0, 0, 0);
+//  * Two-level accumulation: the 32-deep K-tile is summed by the MFMA chain into fresh accumulators
+//    (C = 0), which are then added to the running sums on the VALU.  A single f32 fma chain over
+//    K = 9*2048 products has a ~sqrt(K) rounding walk; chains of 32 + K/32 keep the contraction at the
+//    accuracy of a blocked CPU GEMM.
+//  * The MFMA pipe (64 cycles per instruction) is the roof, so everything else is issued in its shadow:
+//    operand ds_reads run one k-step ahead (double-buffered registers); `mid(p)`, p = 0..7, is called
+//    between k-steps 4..11 and stages 1/8 of the NEXT K-tile into the other LDS buffer; the last four
+//    k-steps run accumulator-major so that the c += t adds of three accumulators overlap the MFMAs of
+//    the next one.
+// Written as a macro (not a function taking a closure): nested lambdas that capture the staging registers by
+// reference made hipcc materialise the closures -- and everything they point to -- in scratch memory.
+// MID(pc) is a statement macro of the enclosing kernel; pc is a compile-time constant after unrolling.
+#define GLF_MMA_KTILE(LDA_, LDB_, a_s, b_s, MID)                                                              \
+    {                                                                                                         \
+        constexpr int NS_ = BK / 2, HEAD_ = NS_ - 4;                                                          \
+        f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};                                                    \
+        float a0_[2], a1_[2], b0_[2], b1_[2];                                                                 \
+        float ta0_[4], ta1_[4], tb0_[4], tb1_[4];                                                             \
+        a0_[0] = (a_s)[0]; a1_[0] = (a_s)[32]; b0_[0] = (b_s)[0]; b1_[0] = (b_s)[32];                         \
+        _Pragma("unroll") for (int st = 0; st < HEAD_; ++st) {                                                \
+            const int cur = st & 1, nxt = cur ^ 1;                                                            \
+            if (st + 1 < HEAD_) {                                                                             \
+                a0_[nxt] = (a_s)[(2 * st + 2) * LDA_]; a1_[nxt] = (a_s)[(2 * st + 2) * LDA_ + 32];            \
+                b0_[nxt] = (b_s)[(2 * st + 2) * LDB_]; b1_[nxt] = (b_s)[(2 * st + 2) * LDB_ + 32];            \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+                    ta0_[q] = (a_s)[(2 * (HEAD_ + q)) * LDA_]; ta1_[q] = (a_s)[(2 * (HEAD_ + q)) * LDA_ + 32]; \
+                    tb0_[q] = (b_s)[(2 * (HEAD_ + q)) * LDB_]; tb1_[q] = (b_s)[(2 * (HEAD_ + q)) * LDB_ + 32]; \
+                }                                                                                             \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of this step's MFMAs */             \
+            t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[cur], b0_[cur], t00, 0, 0, 0);                     \
+            t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[cur], b1_[cur], t01, 0, 0, 0);                     \
+            t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[cur], b0_[cur], t10, 0, 0, 0);                     \
+            t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[cur], b1_[cur], t11, 0, 0, 0);                     \
+            if (st >= HEAD_ - 8) { MID(st - (HEAD_ - 8)) }                                                    \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta0_[q], tb0_[q], t00, 0, 0, 0); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta0_[q], tb1_[q], t01, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        c00 += t00;                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta1_[q], tb0_[q], t10, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        c01 += t01;                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta1_[q], tb1_[q], t11, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        c10 += t10;                                                                                           \
+        c11 += t11;                                                                                           \
     }
-    c00 += t00; c01 += t01; c10 += t10; c11 += t11;
-}
 
 __device__ __forceinline__ void scatter4(float* dst, int ld, const float4& v) {
     dst[0] = v.x; dst[ld] = v.y; dst[2 * ld] = v.z; dst[3 * ld] = v.w;
@@ -111,7 +156,19 @@ __device__ __forceinline__ void scatter4(float* dst, int ld, const float4& v) {
 // BMODE 0: B_tap[n][k]; BMODE 1: B_tap[k][n]
 // ----------------------------------------------------------------------------------------
 template <int BMODE, bool GATHER>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs args) {
+    // ---- scalar copies of the launch arguments (see GeoS) ----
+    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
+    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate, p_split = args.split;
+    const int p_tiles_n = args.tiles_n, p_vec_a = args.vec_a, p_vec_b = args.vec_b;
+    const unsigned p_tap_mask = args.tap_mask;
+    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
+    const float p_alpha = args.alpha;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B; const float* __restrict__ p_bias = args.bias;
+    float* __restrict__ p_C = args.C;
+    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
+    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDA = LD_T;
     constexpr int LDB = (BMODE == 0) ? LD_T : LD_V;
@@ -123,11 +180,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
     const int bz = blockIdx.z;
-    const float* __restrict__ A = p.A + (long long)bz * p.bsa;
-    const float* __restrict__ B = p.B + (long long)bz * p.bsb;
-    float* __restrict__ C = p.C + (long long)bz * p.bsc;
+    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    float* __restrict__ C = p_C + (long long)bz * p_bsc;
 
     const int ac = tid & 7, ar = tid >> 3;          // k-contiguous staging: 8 float4 per 32-deep row
     const int bc = tid & 31, br = tid >> 5;         // row-contiguous staging (BMODE 1)
@@ -138,20 +195,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
     for (int j = 0; j < 4; ++j) {
         const int m = tm * BM + ar + 32 * j;
         if (GATHER) {
-            if (m < p.M) {
-                const int hw = p.g.hd * p.g.wd;
+            if (m < pM) {
+                const int hw = g_hd * g_wd;
                 const int n = m / hw, rem = m - n * hw;
-                a_n[j] = n; a_y[j] = rem / p.g.wd; a_x[j] = rem - a_y[j] * p.g.wd;
+                a_n[j] = n; a_y[j] = rem / g_wd; a_x[j] = rem - a_y[j] * g_wd;
             } else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
             a_off[j] = -1;
         } else {
             a_n[j] = 0; a_y[j] = 0; a_x[j] = 0;
-            a_off[j] = (m < p.M) ? (long long)m * p.lda : -1;
+            a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
         }
     }
 
-    unsigned mask = p.tap_mask;
-    if (GATHER && p.taps > 1) {
+    unsigned mask = p_tap_mask;
+    if (GATHER && p_taps > 1) {
         if (tid == 0) *s_mask = 0u;
         __syncthreads();
         if (ac == 0) {
@@ -160,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
                 const int t = __ffs(mm) - 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (a_n[j] >= 0 && map_src(p.g, p.gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
+                    if (a_n[j] >= 0 && map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
             }
             if (local) atomicOr(s_mask, local);
         }
@@ -168,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
         mask &= *s_mask;
     }
 
-    const int nkc = (p.K + BK - 1) / BK;
+    const int nkc = (pK + BK - 1) / BK;
     const int ntiles = __popc(mask) * nkc;
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
@@ -176,9 +233,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
     float4 ra[4], rb[4];
     unsigned rem_mask = mask;
     int tap = -1, kc = nkc;          // "before the first tile"
-    const bool vec_a = p.vec_a, vec_b = p.vec_b;
+    const bool vec_a = p_vec_a, vec_b = p_vec_b;
 
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         if (++kc >= nkc) {
             kc = 0;
             tap = __ffs(rem_mask) - 1;
@@ -186,62 +243,130 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
             if (GATHER) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    int s = (a_n[j] >= 0) ? map_src(p.g, p.gather, a_n[j], a_y[j], a_x[j], tap) : -1;
-                    a_off[j] = (s >= 0) ? (long long)s * p.lda : -1;
+                    int s = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
+                    a_off[j] = (s >= 0) ? (long long)s * p_lda : -1;
                 }
             }
         }
     };
-    auto load_tile = [&]() {
+    // Fast path (block-uniform): every float4 is in range and 16-byte aligned, so the eight loads of a tile are
+    // issued unconditionally from clamped addresses; rows that are padding / out of range are zeroed by a
+    // select when the registers are written to LDS (store_piece), i.e. AFTER the loads' latency has been
+    // hidden under MFMAs -- a select at load time would make the wave wait for the data right there.  Loads inside per-lane
+    // branches make hipcc wait vmcnt(0) at every merge -- eight serialised L2 round trips per K-tile, measured
+    // as a 20 % loss on the whole kernel.
+    const bool fast = vec_a && vec_b && (pK % BK) == 0 && (BMODE == 0 || (pN % 4) == 0);
+    auto load_tile = [&]() __attribute__((always_inline)) {
         const int kbase = kc * BK + 4 * ac;
+        const float* Bt = B + (long long)tap * p_tsb;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const float4*>(A + (a_off[j] >= 0 ? a_off[j] : 0) + kbase);
+            }
+            if (BMODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tn * BN + ar + 32 * j;
+                    rb[j] = *reinterpret_cast<const float4*>(Bt + (long long)min(n, pN - 1) * p_ldb + kbase);
+                }
+            } else {
+                const int n0 = tn * BN + 4 * bc;
+                const int n0c = min(n0, pN - 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kc * BK + br + 8 * j;          // < K on the fast path
+                    rb[j] = *reinterpret_cast<const float4*>(Bt + (long long)k * p_ldb + n0c);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            ra[j] = (a_off[j] >= 0) ? ld4(A + a_off[j] + kbase, p.K - kbase, vec_a) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* Bt = B + (long long)tap * p.tap_stride_b;
+            ra[j] = (a_off[j] >= 0) ? ld4(A + a_off[j] + kbase, pK - kbase, vec_a) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (BMODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = tn * BN + ar + 32 * j;
-                rb[j] = (n < p.N) ? ld4(Bt + (long long)n * p.ldb + kbase, p.K - kbase, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[j] = (n < pN) ? ld4(Bt + (long long)n * p_ldb + kbase, pK - kbase, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const int n0 = tn * BN + 4 * bc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kc * BK + br + 8 * j;
-                rb[j] = (k < p.K) ? ld4(Bt + (long long)k * p.ldb + n0, p.N - n0, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[j] = (k < pK) ? ld4(Bt + (long long)k * p_ldb + n0, pN - n0, vec_b) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto store_tile = [&](int buf) {
-        float* a_d = As + buf * A_SZ + (4 * ac) * LDA + ar;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) scatter4(a_d + 32 * j, LDA, ra[j]);
-        if (BMODE == 0) {
-            float* b_d = Bs + buf * B_SZ + (4 * ac) * LDB + ar;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) scatter4(b_d + 32 * j, LDB, rb[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(Bs + buf * B_SZ + (br + 8 * j) * LDB + 4 * bc) = rb[j];
-        }
-    };
+    // piece p of the staged tile -> LDS (p < 4: A float4 #p, else B float4 #(p-4)); static indices only
+    // constant array indices only (a lambda parameter index sends ra/rb/a_off to scratch: 3x slower)
+#define GLF_SP_A(J)                                                                          \
+    {                                                                                        \
+        const float4 v = keep_if(!fast || a_off[J] >= 0, ra[J]);                                    \
+        scatter4(As + buf * A_SZ + (4 * ac) * LDA + ar + 32 * J, LDA, v);                    \
+    }
+#define GLF_SP_B(J)                                                                          \
+    {                                                                                        \
+        if (BMODE == 0) {                                                                    \
+            const float4 v = keep_if(!fast || tn * BN + ar + 32 * J < pN, rb[J]);         \
+            scatter4(Bs + buf * B_SZ + (4 * ac) * LDB + ar + 32 * J, LDB, v);                \
+        } else {                                                                             \
+            const float4 v = keep_if(!fast || tn * BN + 4 * bc < pN, rb[J]);              \
+            *reinterpret_cast<float4*>(Bs + buf * B_SZ + (br + 8 * J) * LDB + 4 * bc) = v;   \
+        }                                                                                    \
+    }
+#define GLF_SP(pc)                       \
+    switch (pc) {                        \
+        case 0: GLF_SP_A(0) break;       \
+        case 1: GLF_SP_A(1) break;       \
+        case 2: GLF_SP_A(2) break;       \
+        case 3: GLF_SP_A(3) break;       \
+        case 4: GLF_SP_B(0) break;       \
+        case 5: GLF_SP_B(1) break;       \
+        case 6: GLF_SP_B(2) break;       \
+        default: GLF_SP_B(3) break;      \
+    }
+#define GLF_SP_NEXT(pc) if (has_next) { GLF_SP(pc) }
+#define GLF_SP_NONE(pc)
 
     if (ntiles > 0) {
         advance();
         load_tile();
-        store_tile(0);
+        {
+            const int buf = 0;
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) { GLF_SP(pc) }
+        }
         __syncthreads();
         const int a_lane = (lane >> 5) * LDA + wm + (lane & 31);
         const int b_lane = (lane >> 5) * LDB + wn + (lane & 31);
         for (int it = 0; it < ntiles; ++it) {
             const int buf = it & 1;
             const bool has_next = (it + 1) < ntiles;
+#if GLF_EXP == 1
+            if (has_next) { advance(); }
+#else
             if (has_next) { advance(); load_tile(); }
-            mma_ktile<LDA, LDB>(As + buf * A_SZ + a_lane, Bs + buf * B_SZ + b_lane, c00, c01, c10, c11);
-            if (has_next) store_tile(buf ^ 1);
+#endif
+            // the next tile is written into the other buffer between the MFMAs of this one (nobody reads
+            // buf^1 after the previous barrier); `has_next` is block-uniform
+            {
+                const float* a_sp = As + buf * A_SZ + a_lane;
+                const float* b_sp = Bs + buf * B_SZ + b_lane;
+                const int cbuf = buf;
+                {
+                    const int buf = cbuf ^ 1;      // GLF_SP writes the OTHER buffer
+#if GLF_EXP == 2
+                    GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_SP_NONE)
+#else
+                    GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_SP_NEXT)
+#endif
+                }
+            }
+#if GLF_EXP != 3
             __syncthreads();
+#endif
         }
     }
 
@@ -249,15 +374,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
-        if (col >= p.N) return;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        if (col >= pN) return;
+        const float bv = p_bias ? p_bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row < p.M) {
-                float* dst = C + (long long)row * p.ldc + col;
-                float v = p.alpha * acc[r] + bv;
-                if (p.accumulate) v += *dst;
+            if (row < pM) {
+                float* dst = C + (long long)row * p_ldc + col;
+                float v = p_alpha * acc[r] + bv;
+                if (p_accumulate) v += *dst;
                 *dst = v;
             }
         }
@@ -270,7 +395,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs p
 // grid: x = tiles_m*tiles_n, y = active taps, z = batch*split
 // ----------------------------------------------------------------------------------------
 template <bool GATHER>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs args) {
+    // ---- scalar copies of the launch arguments (see GeoS) ----
+    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
+    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate, p_split = args.split;
+    const int p_tiles_n = args.tiles_n, p_vec_a = args.vec_a, p_vec_b = args.vec_b;
+    const unsigned p_tap_mask = args.tap_mask;
+    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
+    const float p_alpha = args.alpha;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B; const float* __restrict__ p_bias = args.bias;
+    float* __restrict__ p_C = args.C;
+    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
+    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LD = LD_V;
     constexpr int T_SZ = BK * LD;
@@ -281,69 +418,106 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
     // nth set bit of the tap mask
     int tap;
     {
-        unsigned mm = p.tap_mask;
+        unsigned mm = p_tap_mask;
         for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
         tap = __ffs(mm) - 1;
     }
-    const int bz = blockIdx.z / p.split, sl = blockIdx.z - bz * p.split;
-    const float* __restrict__ A = p.A + (long long)bz * p.bsa;
-    const float* __restrict__ B = p.B + (long long)bz * p.bsb;
-    float* __restrict__ C = p.C + (long long)bz * p.bsc + (long long)tap * p.tap_stride_b;
+    const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
+    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
 
-    int chunk = (p.K + p.split - 1) / p.split;
+    int chunk = (pK + p_split - 1) / p_split;
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
-    const int r1 = min(p.K, r0 + chunk);
+    const int r1 = min(pK, r0 + chunk);
     if (r0 >= r1) return;                                      // block-uniform
 
     const int c4 = tid & 31, rr = tid >> 5;
     const int m0 = tm * BM + 4 * c4, n0 = tn * BN + 4 * c4;
-    const bool vec_a = p.vec_a, vec_b = p.vec_b;
-    const int hw = GATHER ? p.g.hd * p.g.wd : 1;
+    const bool vec_a = p_vec_a, vec_b = p_vec_b;
+    const int hw = GATHER ? g_hd * g_wd : 1;
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     float4 ra[4], rb[4];
     int rvalid[4];
 
-    auto load_tile = [&](int rbase) {
+    const bool fast = vec_a && vec_b && (pM % 4) == 0 && (pN % 4) == 0;
+    const int m0c = min(m0, pM - 4), n0c = min(n0, pN - 4);
+    auto load_tile = [&](int rbase) __attribute__((always_inline)) {
+        long long src[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = rbase + rr + 8 * j;
-            long long src = -1;
+            src[j] = -1;
             if (r < r1) {
                 if (GATHER) {
                     const int n = r / hw, rem = r - n * hw;
-                    const int y = rem / p.g.wd, x = rem - y * p.g.wd;
-                    src = map_src(p.g, 1, n, y, x, tap);
+                    const int y = rem / g_wd, x = rem - y * g_wd;
+                    src[j] = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, n, y, x, tap);
                 } else {
-                    src = r;
+                    src[j] = r;
                 }
             }
-            rvalid[j] = src >= 0;
-            if (src >= 0) {
-                ra[j] = ld4(A + (long long)r * p.lda + m0, p.M - m0, vec_a);
-                rb[j] = ld4(B + src * p.ldb + n0, p.N - n0, vec_b);
+            rvalid[j] = src[j] >= 0;
+        }
+        if (fast) {          // unconditional loads from clamped addresses + select (see gemm_rows_kernel)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = min(rbase + rr + 8 * j, r1 - 1);
+                const float4 va = *reinterpret_cast<const float4*>(A + (long long)r * p_lda + m0c);
+                const float4 vb = *reinterpret_cast<const float4*>(B + (src[j] >= 0 ? src[j] : 0) * p_ldb + n0c);
+                ra[j] = va;                  // zeroed at store time (rvalid / column range), not here
+                rb[j] = vb;
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rbase + rr + 8 * j;
+            if (src[j] >= 0) {
+                ra[j] = ld4(A + (long long)r * p_lda + m0, pM - m0, vec_a);
+                rb[j] = ld4(B + src[j] * p_ldb + n0, pN - n0, vec_b);
             } else {
                 ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<float4*>(As + buf * T_SZ + (rr + 8 * j) * LD + 4 * c4) = ra[j];
-            *reinterpret_cast<float4*>(Bs + buf * T_SZ + (rr + 8 * j) * LD + 4 * c4) = rb[j];
-            if (c4 == 0) vflag[buf * 32 + rr + 8 * j] = rvalid[j];
-        }
-    };
+#define GLF_TP_A(J)                                                                          \
+    {                                                                                        \
+        const float4 v = keep_if(!fast || (rvalid[J] && m0 < pM), ra[J]);                 \
+        *reinterpret_cast<float4*>(As + buf * T_SZ + (rr + 8 * J) * LD + 4 * c4) = v;        \
+        if (c4 == 0) vflag[buf * 32 + rr + 8 * J] = rvalid[J];                               \
+    }
+#define GLF_TP_B(J)                                                                          \
+    {                                                                                        \
+        const float4 v = keep_if(!fast || (rvalid[J] && n0 < pN), rb[J]);                 \
+        *reinterpret_cast<float4*>(Bs + buf * T_SZ + (rr + 8 * J) * LD + 4 * c4) = v;        \
+    }
+#define GLF_TP(pc)                       \
+    switch (pc) {                        \
+        case 0: GLF_TP_A(0) break;       \
+        case 1: GLF_TP_A(1) break;       \
+        case 2: GLF_TP_A(2) break;       \
+        case 3: GLF_TP_A(3) break;       \
+        case 4: GLF_TP_B(0) break;       \
+        case 5: GLF_TP_B(1) break;       \
+        case 6: GLF_TP_B(2) break;       \
+        default: GLF_TP_B(3) break;      \
+    }
+#define GLF_TP_NEXT(pc) if (has_next) { GLF_TP(pc) }
 
     load_tile(r0);
-    store_tile(0);
+    {
+        const int buf = 0;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) { GLF_TP(pc) }
+    }
     __syncthreads();
     const int a_lane = (lane >> 5) * LD + wm + (lane & 31);
     const int b_lane = (lane >> 5) * LD + wn + (lane & 31);
@@ -354,23 +528,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs p) 
         if (has_next) load_tile(rbase + BK);
         // all 32 rows of this K-tile in the padding (dilated taps): nothing to add
         const bool any = __ballot(vflag[buf * 32 + (lane & 31)] != 0) != 0ull;
-        if (any)
-            mma_ktile<LD, LD>(As + buf * T_SZ + a_lane, Bs + buf * T_SZ + b_lane, c00, c01, c10, c11);
-        if (has_next) store_tile(buf ^ 1);
+        {
+            const float* a_sp = As + buf * T_SZ + a_lane;
+            const float* b_sp = Bs + buf * T_SZ + b_lane;
+            const int cbuf = buf;
+            const int buf = cbuf ^ 1;              // GLF_TP writes the OTHER buffer
+            if (any) {
+                GLF_MMA_KTILE(LD, LD, a_sp, b_sp, GLF_TP_NEXT)
+            } else if (has_next) {
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) { GLF_TP(pc) }
+            }
+        }
         __syncthreads();
     }
 
-    const bool atomic = (p.split > 1) || p.accumulate;
+    const bool atomic = (p_split > 1) || p_accumulate;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
-        if (col >= p.N) return;
+        if (col >= pN) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row < p.M) {
-                float* dst = C + (long long)row * p.ldc + col;
-                const float v = p.alpha * acc[r];
+            if (row < pM) {
+                float* dst = C + (long long)row * p_ldc + col;
+                const float v = p_alpha * acc[r];
                 if (atomic) atomicAdd(dst, v); else *dst = v;
             }
         }

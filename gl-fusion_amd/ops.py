@@ -143,7 +143,8 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         # dense, reference-equivalent FLOPs of this launch (every tap, padding included) and the FLOPs of the
         # taps the host-side mask keeps
         dense = 2.0 * M * N * K * taps * batch
-        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * bin(mask).count("1") / taps, ev0, ev1))
+        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * bin(mask).count("1") / taps, ev0, ev1,
+                     (M, N, K, taps, bin(mask).count("1"), batch, split, geo[8] if geo else 0, geo[9] if geo else 0)))
 
 
 def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
