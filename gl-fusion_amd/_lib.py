@@ -29,7 +29,7 @@ class GemmParams(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
         ("batch", C.c_int32),
         ("batch_stride_a", C.c_int64), ("batch_stride_b", C.c_int64), ("batch_stride_c", C.c_int64),
-        ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32),
+        ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32), ("rect", C.c_int32),
     ]
 
 

@@ -46,6 +46,7 @@ struct GemmArgs {
     int accumulate, split;
     int tiles_m, tiles_n;
     int vec_a, vec_b;
+    int rect;       // tap-parallel rectangle mode (see tap_rect)
 };
 
 // Scalar copy of the conv geometry: kernels keep it (and every other GemmArgs field they use) in local
@@ -83,6 +84,22 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
     if (nvalid > 2) v.z = p[2];
     if (nvalid > 3) v.w = p[3];
     return v;
+}
+
+// Rectangle of destination pixels for which `tap` reads inside the source map (stride 1 only):
+//   gather 1: 0 <= y - pad + ky*dil < hs ;  gather 2: 0 <= y + pad - ky*dil < hs.
+// ASPP's rate-12/24 3x3 convs on a 28x28 map spend most taps in the padding (in-bounds fractions 51 % / 18 %);
+// in rect mode every tap becomes its own GEMM over exactly its rectangle (rows enumerate the rectangle, no
+// padding work at all) and the per-tap results are summed with float atomics into a zero-filled output.
+__host__ __device__ inline void tap_rect(int gather, int tap, int kw, int pad, int dil, int hs, int ws, int hd, int wd,
+                                         int& y0, int& y1, int& x0, int& x1) {
+    const int ky = tap / kw, kx = tap - ky * kw;
+    const int oy = (gather == 1) ? pad - ky * dil : ky * dil - pad;
+    const int ox = (gather == 1) ? pad - kx * dil : kx * dil - pad;
+    y0 = oy > 0 ? oy : 0;           y1 = hs + oy < hd ? hs + oy : hd;
+    x0 = ox > 0 ? ox : 0;           x1 = ws + ox < wd ? ws + ox : wd;
+    if (y1 < y0) y1 = y0;
+    if (x1 < x0) x1 = x0;
 }
 
 // value select (a `cond ? reg4 : make_float4(0.f, 0.f, 0.f, 0.f)` on two lvalues becomes a pointer select through scratch)
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
     float* __restrict__ p_C = args.C;
     const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
     const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDA = LD_T;
@@ -180,7 +198,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
+    const int tn = bid % p_tiles_n;
+    int tm = bid / p_tiles_n;
+    int pMe = pM;                                   // rows of this block's GEMM (rect mode: its tap's rectangle)
+    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd;
+    unsigned mask = p_tap_mask;
+    if (p_rect) {                                   // tiles are laid out tap after tap
+        for (unsigned mm = p_tap_mask; mm; mm &= mm - 1) {
+            const int t = __ffs(mm) - 1;
+            int y0, y1, x0, x1;
+            tap_rect(p_gather, t, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
+            const int mt = g_nimg * (y1 - y0) * (x1 - x0);
+            const int tiles = (mt + BM - 1) / BM;
+            if (tm < tiles || (mm & (mm - 1)) == 0) { mask = 1u << t; pMe = mt; r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0; break; }
+            tm -= tiles;
+        }
+    }
     const int bz = blockIdx.z;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
@@ -195,10 +228,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
     for (int j = 0; j < 4; ++j) {
         const int m = tm * BM + ar + 32 * j;
         if (GATHER) {
-            if (m < pM) {
-                const int hw = g_hd * g_wd;
+            if (m < pMe) {
+                const int hw = r_h * r_w;
                 const int n = m / hw, rem = m - n * hw;
-                a_n[j] = n; a_y[j] = rem / g_wd; a_x[j] = rem - a_y[j] * g_wd;
+                const int yy = rem / r_w;
+                a_n[j] = n; a_y[j] = r_y0 + yy; a_x[j] = r_x0 + rem - yy * r_w;
             } else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
             a_off[j] = -1;
         } else {
@@ -207,8 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
         }
     }
 
-    unsigned mask = p_tap_mask;
-    if (GATHER && p_taps > 1) {
+    if (GATHER && p_taps > 1 && !p_rect) {
         if (tid == 0) *s_mask = 0u;
         __syncthreads();
         if (ac == 0) {
@@ -379,11 +412,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row < pM) {
-                float* dst = C + (long long)row * p_ldc + col;
-                float v = p_alpha * acc[r] + bv;
-                if (p_accumulate) v += *dst;
-                *dst = v;
+            if (row < pMe) {
+                if (p_rect) {                               // rectangle row -> output pixel; taps meet in atomics
+                    const int hw = r_h * r_w;
+                    const int n = row / hw, rem = row - n * hw;
+                    const int yy = rem / r_w;
+                    const long long orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+                    atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
+                } else {
+                    float* dst = C + (long long)row * p_ldc + col;
+                    float v = p_alpha * acc[r] + bv;
+                    if (p_accumulate) v += *dst;
+                    *dst = v;
+                }
             }
         }
     };
@@ -407,6 +448,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
     float* __restrict__ p_C = args.C;
     const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
     const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LD = LD_V;
@@ -431,16 +473,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
     float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
 
-    int chunk = (pK + p_split - 1) / p_split;
+    // rect mode: the reduction runs over this tap's rectangle of output pixels only (see tap_rect)
+    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
+    if (p_rect) {
+        int y0, y1, x0, x1;
+        tap_rect(1, tap, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
+        r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
+        pKe = g_nimg * r_h * r_w;
+    }
+    int chunk = (pKe + p_split - 1) / p_split;
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
-    const int r1 = min(pK, r0 + chunk);
+    const int r1 = min(pKe, r0 + chunk);
     if (r0 >= r1) return;                                      // block-uniform
 
     const int c4 = tid & 31, rr = tid >> 5;
     const int m0 = tm * BM + 4 * c4, n0 = tn * BN + 4 * c4;
     const bool vec_a = p_vec_a, vec_b = p_vec_b;
-    const int hw = GATHER ? g_hd * g_wd : 1;
+    const int hw = GATHER ? r_h * r_w : 1;
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     float4 ra[4], rb[4];
@@ -449,27 +499,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
     const bool fast = vec_a && vec_b && (pM % 4) == 0 && (pN % 4) == 0;
     const int m0c = min(m0, pM - 4), n0c = min(n0, pN - 4);
     auto load_tile = [&](int rbase) __attribute__((always_inline)) {
-        long long src[4];
+        long long src[4], arow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = rbase + rr + 8 * j;
             src[j] = -1;
-            if (r < r1) {
-                if (GATHER) {
-                    const int n = r / hw, rem = r - n * hw;
-                    const int y = rem / g_wd, x = rem - y * g_wd;
-                    src[j] = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, n, y, x, tap);
-                } else {
-                    src[j] = r;
-                }
+            arow[j] = min(r, r1 - 1);
+            if (GATHER) {
+                const int rc = min(r, r1 - 1);
+                const int n = rc / hw, rem = rc - n * hw;
+                const int yy = rem / r_w;
+                const int y = r_y0 + yy, x = r_x0 + rem - yy * r_w;
+                arow[j] = ((long long)n * g_hd + y) * g_wd + x;
+                if (r < r1) src[j] = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, n, y, x, tap);
+            } else if (r < r1) {
+                src[j] = r;
             }
             rvalid[j] = src[j] >= 0;
         }
         if (fast) {          // unconditional loads from clamped addresses + select (see gemm_rows_kernel)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r = min(rbase + rr + 8 * j, r1 - 1);
-                const float4 va = *reinterpret_cast<const float4*>(A + (long long)r * p_lda + m0c);
+                const float4 va = *reinterpret_cast<const float4*>(A + arow[j] * p_lda + m0c);
                 const float4 vb = *reinterpret_cast<const float4*>(B + (src[j] >= 0 ? src[j] : 0) * p_ldb + n0c);
                 ra[j] = va;                  // zeroed at store time (rvalid / column range), not here
                 rb[j] = vb;
@@ -478,9 +529,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = rbase + rr + 8 * j;
             if (src[j] >= 0) {
-                ra[j] = ld4(A + (long long)r * p_lda + m0, pM - m0, vec_a);
+                ra[j] = ld4(A + arow[j] * p_lda + m0, pM - m0, vec_a);
                 rb[j] = ld4(B + src[j] * p_ldb + n0, pN - n0, vec_b);
             } else {
                 ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -592,8 +642,28 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.bsa = p->batch_stride_a; a.bsb = p->batch_stride_b; a.bsc = p->batch_stride_c;
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
-    a.vec_a = 0; a.vec_b = 0;
+    a.vec_a = 0; a.vec_b = 0; a.rect = 0;
     return a;
+}
+
+// rect mode (tap-parallel rectangles): validates and sizes the grid as the sum over taps of their tiles
+int setup_rect(const glf_gemm_params* p, const float* bias, GemmArgs& a, dim3& grid, const char* who) {
+    GLF_REQUIRE(p->gather == 1 || p->gather == 2, GLF_ERR_BAD_SHAPE, "%s: rect mode needs a conv gather", who);
+    GLF_REQUIRE(p->stride == 1, GLF_ERR_UNSUPPORTED, "%s: rect mode needs stride 1", who);
+    GLF_REQUIRE(bias == nullptr && !p->accumulate && p->batch == 1, GLF_ERR_UNSUPPORTED,
+                "%s: rect mode takes no bias / accumulate / batch (C must be zero-filled by the caller)", who);
+    long long tiles = 0;
+    for (unsigned mm = p->tap_mask; mm; mm &= mm - 1) {
+        const int t = __builtin_ctz(mm);
+        int y0, y1, x0, x1;
+        tap_rect(p->gather, t, p->kw, p->pad, p->dil, p->hs, p->ws, p->hd, p->wd, y0, y1, x0, x1);
+        const long long mt = (long long)p->n_img * (y1 - y0) * (x1 - x0);
+        tiles += (mt + BM - 1) / BM;
+    }
+    GLF_REQUIRE(tiles > 0 && tiles * a.tiles_n < 2147483647LL, GLF_ERR_BAD_SHAPE, "%s: rect mode grid out of range", who);
+    a.rect = 1;
+    grid = dim3((unsigned)(tiles * a.tiles_n), 1, 1);
+    return GLF_OK;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -628,6 +698,9 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
+    if (p->rect) {
+        if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
+    }
     if (p->gather)
         hipLaunchKernelGGL((gemm_rows_kernel<0, true>), grid, dim3(NTHREADS), SMEM_ROWS_NT, glf::S(stream), a);
     else
@@ -646,6 +719,9 @@ extern "C" int glf_gemm_nn(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
+    if (p->rect) {
+        if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nn")) return rc;
+    }
     if (p->gather)
         hipLaunchKernelGGL((gemm_rows_kernel<1, true>), grid, dim3(NTHREADS), SMEM_ROWS_NN, glf::S(stream), a);
     else
@@ -666,6 +742,11 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
     GLF_REQUIRE((long long)p->batch * a.split <= 65535, GLF_ERR_BAD_SHAPE, "gemm_tn: batch*split too large");
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0);
+    if (p->rect) {
+        GLF_REQUIRE(p->gather == 1 && p->stride == 1 && p->batch == 1, GLF_ERR_UNSUPPORTED,
+                    "gemm_tn: rect mode needs a stride-1 forward conv gather and batch 1");
+        a.rect = 1;
+    }
     dim3 grid(a.tiles_m * a.tiles_n, ntap, p->batch * a.split);
     if (p->gather)
         hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);

@@ -114,7 +114,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          lda: int, ldb: int, ldc: int, bias: Optional[torch.Tensor] = None, taps: int = 1, mask: int = 1,
          tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
-         split: int = 1) -> None:
+         split: int = 1, rect: bool = False) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil)."""
     p = GemmParams()
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
@@ -124,7 +124,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     else:
         (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
     p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
-    p.alpha, p.accumulate, p.split = alpha, int(accumulate), split
+    p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -193,6 +193,34 @@ def tap_major(weight: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------
 # conv2d (NHWC, implicit GEMM)
 # ----------------------------------------------------------------------------------------
+_rect_cache = {}
+
+
+def rect_fraction(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, pad: int, dil: int, mask: int) -> float:
+    """sum over kept taps of (in-range rectangle area) / (kept taps x full area), stride 1 (mirrors tap_rect
+    in gemm_f32.hip).  Small values = most tap work is padding => the tap-parallel rect mode pays."""
+    key = (gather, hd, wd, hs, ws, kh, kw, pad, dil, mask)
+    f = _rect_cache.get(key)
+    if f is None:
+        tot, n = 0, 0
+        for t in range(kh * kw):
+            if not (mask >> t) & 1:
+                continue
+            ky, kx = divmod(t, kw)
+            oy = pad - ky * dil if gather == 1 else ky * dil - pad
+            ox = pad - kx * dil if gather == 1 else kx * dil - pad
+            rh = max(0, min(hs + oy, hd) - max(oy, 0))
+            rw = max(0, min(ws + ox, wd) - max(ox, 0))
+            tot += rh * rw
+            n += 1
+        f = tot / max(1, n * hd * wd)
+        _rect_cache[key] = f
+    return f
+
+
+RECT_THRESHOLD = 0.8     # use rect mode when less than this fraction of the kept taps' work is in range
+
+
 def _conv_out(h: int, k: int, stride: int, pad: int, dil: int) -> int:
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -217,8 +245,12 @@ class Conv2dFn(Function):
         plain = taps == 1 and stride == 1 and pad == 0
         geo = (n, h, w, ho, wo, kh, kw, stride, pad, dil)
         mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+        rect = (not plain and taps > 1 and stride == 1 and bias is None and bin(mask).count("1") > 1
+                and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+        if rect:
+            y.zero_()
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
-             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo)
+             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect)
         ctx.save_for_backward(x, wt)
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
         return y
@@ -237,19 +269,24 @@ class Conv2dFn(Function):
             if mask == 0:
                 dx = torch.zeros_like(x)
             else:
-                dx = torch.empty_like(x)
+                rect = (not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1
+                        and rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+                dx = torch.zeros_like(x) if rect else torch.empty_like(x)
                 gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                      tap_stride_b=cout * cin, gather=0 if plain else 2,
-                     geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil))
+                     geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
         if ctx.needs_input_grad[1]:
             mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
             ntap = bin(mask).count("1")
-            split = _tn_split(rows_o, cout, cin, ntap)
+            rect = (not plain and taps > 1 and stride == 1 and ntap > 1
+                    and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+            frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
+            split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
             full = mask == (1 << taps) - 1
             dwt = (torch.empty if (split == 1 and full) else torch.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
             gemm("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
-                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split)
+                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect)
             if taps == 1:
                 dw = dwt.view(wshape)
             else:

@@ -60,7 +60,7 @@ size_t glf_sizeof_gemm_params(void);
  *             source pixel (y*stride - pad + ky*dil, x*stride - pad + kx*dil) on the hs x ws grid
  *         2 = transposed mapping (dgrad): row m = input pixel (n,y,x) on hd x wd reads the
  *             output-gradient pixel ((y + pad - ky*dil)/stride, ...) on hs x ws when divisible
- * Out-of-range taps read zeros; taps invalid for a whole 128-row tile are skipped.
+ * Out-of-range taps read zeros; taps invalid for a whole 128-row tile are skipped (or see `rect`).
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t M, N, K;            /* per-tap GEMM extents (see each entry point)                   */
@@ -76,6 +76,11 @@ typedef struct {
     int32_t accumulate;         /* 1: C += result (fwd/dgrad: read-modify-write; wgrad: atomics) */
     int32_t split;              /* wgrad/TN only: number of reduction slices (>=1); >1 requires  */
                                 /* C zero-filled (or holding the value to accumulate onto)       */
+    int32_t rect;               /* 1: tap-parallel rectangle mode (stride-1 convs whose taps fall */
+                                /* mostly into the padding, i.e. ASPP): each tap runs as its own  */
+                                /* GEMM over exactly its in-range rectangle of pixels; nt/nn sum  */
+                                /* the taps with float atomics into a ZERO-FILLED C (no bias); tn */
+                                /* shortens each tap's reduction to its rectangle                 */
 } glf_gemm_params;
 
 /* A[m][k] (k contiguous, rows gathered per `gather`), B_tap[n][k] (k contiguous: torch's
