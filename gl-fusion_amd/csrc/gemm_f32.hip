@@ -125,22 +125,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // Written as a macro (not a function taking a closure): nested lambdas that capture the staging registers by
 // reference made hipcc materialise the closures -- and everything they point to -- in scratch memory.
 // MID(pc) is a statement macro of the enclosing kernel; pc is a compile-time constant after unrolling.
+#if GLF_EXP == 4
+#define GLF_LD(x) (1.0f + (float)(lane))      /* timing experiment: no LDS operand reads */
+#else
+#define GLF_LD(x) (x)
+#endif
+// MID(q), q = 0..11, is called after the MFMAs of head k-step q (HEAD_ = 12).
 #define GLF_MMA_KTILE(LDA_, LDB_, a_s, b_s, MID)                                                              \
     {                                                                                                         \
         constexpr int NS_ = BK / 2, HEAD_ = NS_ - 4;                                                          \
         f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};                                                    \
         float a0_[2], a1_[2], b0_[2], b1_[2];                                                                 \
         float ta0_[4], ta1_[4], tb0_[4], tb1_[4];                                                             \
-        a0_[0] = (a_s)[0]; a1_[0] = (a_s)[32]; b0_[0] = (b_s)[0]; b1_[0] = (b_s)[32];                         \
+        a0_[0] = GLF_LD((a_s)[0]); a1_[0] = GLF_LD((a_s)[32]); b0_[0] = GLF_LD((b_s)[0]); b1_[0] = GLF_LD((b_s)[32]); \
         _Pragma("unroll") for (int st = 0; st < HEAD_; ++st) {                                                \
             const int cur = st & 1, nxt = cur ^ 1;                                                            \
             if (st + 1 < HEAD_) {                                                                             \
-                a0_[nxt] = (a_s)[(2 * st + 2) * LDA_]; a1_[nxt] = (a_s)[(2 * st + 2) * LDA_ + 32];            \
-                b0_[nxt] = (b_s)[(2 * st + 2) * LDB_]; b1_[nxt] = (b_s)[(2 * st + 2) * LDB_ + 32];            \
+                a0_[nxt] = GLF_LD((a_s)[(2 * st + 2) * LDA_]); a1_[nxt] = GLF_LD((a_s)[(2 * st + 2) * LDA_ + 32]); \
+                b0_[nxt] = GLF_LD((b_s)[(2 * st + 2) * LDB_]); b1_[nxt] = GLF_LD((b_s)[(2 * st + 2) * LDB_ + 32]); \
             } else {                                                                                          \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
-                    ta0_[q] = (a_s)[(2 * (HEAD_ + q)) * LDA_]; ta1_[q] = (a_s)[(2 * (HEAD_ + q)) * LDA_ + 32]; \
-                    tb0_[q] = (b_s)[(2 * (HEAD_ + q)) * LDB_]; tb1_[q] = (b_s)[(2 * (HEAD_ + q)) * LDB_ + 32]; \
+                    ta0_[q] = GLF_LD((a_s)[(2 * (HEAD_ + q)) * LDA_]); ta1_[q] = GLF_LD((a_s)[(2 * (HEAD_ + q)) * LDA_ + 32]); \
+                    tb0_[q] = GLF_LD((b_s)[(2 * (HEAD_ + q)) * LDB_]); tb1_[q] = GLF_LD((b_s)[(2 * (HEAD_ + q)) * LDB_ + 32]); \
                 }                                                                                             \
             }                                                                                                 \
             __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ahead of this step's MFMAs */             \
@@ -148,7 +154,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
             t01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[cur], b1_[cur], t01, 0, 0, 0);                     \
             t10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[cur], b0_[cur], t10, 0, 0, 0);                     \
             t11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[cur], b1_[cur], t11, 0, 0, 0);                     \
-            if (st >= HEAD_ - 8) { MID(st - (HEAD_ - 8)) }                                                    \
+            { MID(st) }                                                                                       \
         }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) t00 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta0_[q], tb0_[q], t00, 0, 0, 0); \
@@ -292,28 +298,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
     auto load_tile = [&]() __attribute__((always_inline)) {
         const int kbase = kc * BK + 4 * ac;
         const float* Bt = B + (long long)tap * p_tsb;
-        if (fast) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const float4*>(A + (a_off[j] >= 0 ? a_off[j] : 0) + kbase);
-            }
-            if (BMODE == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = tn * BN + ar + 32 * j;
-                    rb[j] = *reinterpret_cast<const float4*>(Bt + (long long)min(n, pN - 1) * p_ldb + kbase);
-                }
-            } else {
-                const int n0 = tn * BN + 4 * bc;
-                const int n0c = min(n0, pN - 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = kc * BK + br + 8 * j;          // < K on the fast path
-                    rb[j] = *reinterpret_cast<const float4*>(Bt + (long long)k * p_ldb + n0c);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             ra[j] = (a_off[j] >= 0) ? ld4(A + a_off[j] + kbase, pK - kbase, vec_a) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -336,16 +320,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
     // constant array indices only (a lambda parameter index sends ra/rb/a_off to scratch: 3x slower)
 #define GLF_SP_A(J)                                                                          \
     {                                                                                        \
-        const float4 v = keep_if(!fast || a_off[J] >= 0, ra[J]);                                    \
+        const float4 v = ra[J];                                                              \
         scatter4(As + buf * A_SZ + (4 * ac) * LDA + ar + 32 * J, LDA, v);                    \
     }
 #define GLF_SP_B(J)                                                                          \
     {                                                                                        \
         if (BMODE == 0) {                                                                    \
-            const float4 v = keep_if(!fast || tn * BN + ar + 32 * J < pN, rb[J]);         \
+            const float4 v = rb[J];                                                          \
             scatter4(Bs + buf * B_SZ + (4 * ac) * LDB + ar + 32 * J, LDB, v);                \
         } else {                                                                             \
-            const float4 v = keep_if(!fast || tn * BN + 4 * bc < pN, rb[J]);              \
+            const float4 v = rb[J];                                                          \
             *reinterpret_cast<float4*>(Bs + buf * B_SZ + (br + 8 * J) * LDB + 4 * bc) = v;   \
         }                                                                                    \
     }
@@ -360,46 +344,122 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
         case 6: GLF_SP_B(2) break;       \
         default: GLF_SP_B(3) break;      \
     }
-#define GLF_SP_NEXT(pc) if (has_next) { GLF_SP(pc) }
-#define GLF_SP_NONE(pc)
+#define GLF_SP_NEXT(q) if (has_next && (q) >= 4) { GLF_SP((q) - 4) }
+
+    // ---- fast path state: per-thread source pointers advanced incrementally (no per-tile address maths) ----
+    const float* pa[4];
+    const float* pb[4];
+    unsigned a_ok = 0;
+    const long long b_step = (BMODE == 0) ? (long long)BK : (long long)BK * p_ldb;
+    auto advance_fast = [&]() __attribute__((always_inline)) {
+        if (++kc >= nkc) {
+            kc = 0;
+            tap = __ffs(rem_mask) - 1;
+            rem_mask &= rem_mask - 1;
+            a_ok = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                long long off;
+                if (GATHER) {
+                    const int sr = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
+                    off = (sr >= 0) ? (long long)sr * p_lda : -1;
+                } else {
+                    off = a_off[j];
+                }
+                a_ok |= (off >= 0 ? 1u : 0u) << j;
+                pa[j] = A + (off >= 0 ? off : 0) + 4 * ac;
+            }
+            const float* Bt = B + (long long)tap * p_tsb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (BMODE == 0) pb[j] = Bt + (long long)min(tn * BN + ar + 32 * j, pN - 1) * p_ldb + 4 * ac;
+                else pb[j] = Bt + (long long)(br + 8 * j) * p_ldb + min(tn * BN + 4 * bc, pN - 4);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[j] += BK; pb[j] += b_step; }
+        }
+    };
+#define GLF_FLP(pc)                                                                         \
+    switch (pc) {                                                                           \
+        case 0: ra[0] = *reinterpret_cast<const float4*>(pa[0]); break;                     \
+        case 1: ra[1] = *reinterpret_cast<const float4*>(pa[1]); break;                     \
+        case 2: ra[2] = *reinterpret_cast<const float4*>(pa[2]); break;                     \
+        case 3: ra[3] = *reinterpret_cast<const float4*>(pa[3]); break;                     \
+        case 4: rb[0] = *reinterpret_cast<const float4*>(pb[0]); break;                     \
+        case 5: rb[1] = *reinterpret_cast<const float4*>(pb[1]); break;                     \
+        case 6: rb[2] = *reinterpret_cast<const float4*>(pb[2]); break;                     \
+        default: rb[3] = *reinterpret_cast<const float4*>(pb[3]); break;                    \
+    }
+#define GLF_FSP_A(J) scatter4(As + buf * A_SZ + (4 * ac) * LDA + ar + 32 * J, LDA, keep_if((a_ok >> J) & 1u, ra[J]));
+#define GLF_FSP_B(J)                                                                                          \
+    {                                                                                                         \
+        if (BMODE == 0) scatter4(Bs + buf * B_SZ + (4 * ac) * LDB + ar + 32 * J, LDB, keep_if(tn * BN + ar + 32 * J < pN, rb[J])); \
+        else *reinterpret_cast<float4*>(Bs + buf * B_SZ + (br + 8 * J) * LDB + 4 * bc) = keep_if(tn * BN + 4 * bc < pN, rb[J]);    \
+    }
+#define GLF_FSP(pc)                      \
+    switch (pc) {                        \
+        case 0: GLF_FSP_A(0) break;      \
+        case 1: GLF_FSP_A(1) break;      \
+        case 2: GLF_FSP_A(2) break;      \
+        case 3: GLF_FSP_A(3) break;      \
+        case 4: GLF_FSP_B(0) break;      \
+        case 5: GLF_FSP_B(1) break;      \
+        case 6: GLF_FSP_B(2) break;      \
+        default: GLF_FSP_B(3) break;     \
+    }
+    // k-steps 0..3 issue the eight loads of the next tile (two per step), k-steps 4..11 write them to LDS
+#define GLF_FAST_MID(q)                                                       \
+    if (has_next) {                                                           \
+        if ((q) < 4) { GLF_FLP(2 * (q)) GLF_FLP(2 * (q) + 1) }                \
+        else { GLF_FSP((q) - 4) }                                             \
+    }
+#define GLF_NO_MID(q)
 
     if (ntiles > 0) {
-        advance();
-        load_tile();
-        {
-            const int buf = 0;
-#pragma unroll
-            for (int pc = 0; pc < 8; ++pc) { GLF_SP(pc) }
-        }
-        __syncthreads();
         const int a_lane = (lane >> 5) * LDA + wm + (lane & 31);
         const int b_lane = (lane >> 5) * LDB + wn + (lane & 31);
-        for (int it = 0; it < ntiles; ++it) {
-            const int buf = it & 1;
-            const bool has_next = (it + 1) < ntiles;
-#if GLF_EXP == 1
-            if (has_next) { advance(); }
-#else
-            if (has_next) { advance(); load_tile(); }
-#endif
-            // the next tile is written into the other buffer between the MFMAs of this one (nobody reads
-            // buf^1 after the previous barrier); `has_next` is block-uniform
+        if (fast) {
+            advance_fast();
             {
-                const float* a_sp = As + buf * A_SZ + a_lane;
-                const float* b_sp = Bs + buf * B_SZ + b_lane;
-                const int cbuf = buf;
-                {
-                    const int buf = cbuf ^ 1;      // GLF_SP writes the OTHER buffer
-#if GLF_EXP == 2
-                    GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_SP_NONE)
-#else
-                    GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_SP_NEXT)
-#endif
-                }
+                const int buf = 0;
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) { GLF_FLP(pc) }
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) { GLF_FSP(pc) }
             }
-#if GLF_EXP != 3
             __syncthreads();
+            for (int it = 0; it < ntiles; ++it) {
+                const bool has_next = (it + 1) < ntiles;
+                if (has_next) advance_fast();
+                const float* a_sp = As + (it & 1) * A_SZ + a_lane;
+                const float* b_sp = Bs + (it & 1) * B_SZ + b_lane;
+                const int buf = (it & 1) ^ 1;      // the staging macros write the OTHER buffer (free since the last barrier)
+#if GLF_EXP == 2
+                GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_NO_MID)
+#else
+                GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_FAST_MID)
 #endif
+                __syncthreads();
+            }
+        } else {
+            advance();
+            load_tile();
+            {
+                const int buf = 0;
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) { GLF_SP(pc) }
+            }
+            __syncthreads();
+            for (int it = 0; it < ntiles; ++it) {
+                const bool has_next = (it + 1) < ntiles;
+                if (has_next) { advance(); load_tile(); }
+                const float* a_sp = As + (it & 1) * A_SZ + a_lane;
+                const float* b_sp = Bs + (it & 1) * B_SZ + b_lane;
+                const int buf = (it & 1) ^ 1;
+                GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_SP_NEXT)
+                __syncthreads();
+            }
         }
     }
 
@@ -560,7 +620,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
         case 6: GLF_TP_B(2) break;       \
         default: GLF_TP_B(3) break;      \
     }
-#define GLF_TP_NEXT(pc) if (has_next) { GLF_TP(pc) }
+#define GLF_TP_NEXT(q) if (has_next && (q) >= 4) { GLF_TP((q) - 4) }
 
     load_tile(r0);
     {
