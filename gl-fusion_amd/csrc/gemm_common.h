@@ -1,0 +1,148 @@
+// Shared pieces of the contraction kernels (gemm_f32.hip: exact-fp32 MFMA; gemm_bf16s.hip: split-bf16 MFMA).
+#pragma once
+#include "glf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_T = 129;   // LDS row stride of a tile filled by the transposing scatter
+constexpr int LD_V = 132;   // LDS row stride of a tile filled with ds_write_b128
+constexpr int NTHREADS = 256;
+
+struct Geo { int n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil; };
+
+struct GemmArgs {
+    const float* A; const float* B; const float* bias; float* C;
+    int M, N, K, lda, ldb, ldc, taps;
+    unsigned tap_mask;
+    long long tap_stride_b;
+    int gather;
+    Geo g;
+    long long bsa, bsb, bsc;
+    float alpha;
+    int accumulate, split;
+    int tiles_m, tiles_n;
+    int vec_a, vec_b;
+    int rect;       // tap-parallel rectangle mode (see tap_rect)
+};
+
+// Scalar copy of the conv geometry: kernels keep it (and every other GemmArgs field they use) in local
+// scalars -- lambdas that capture the by-value kernel argument struct by reference made hipcc spill the whole
+// struct to scratch and re-load fields from there (3x slower).
+struct GeoS { int hs, ws, hd, wd, kw, stride, pad, dil; };
+
+// source row of GEMM row (n,y,x) for `tap`, or -1 when the tap falls into the padding
+__device__ __forceinline__ int map_src(const int hs, const int ws, const int kw, const int stride, const int pad,
+                                       const int dil, const int gather, int n, int y, int x, int tap) {
+    const int ky = tap / kw, kx = tap - ky * kw;
+    int sy, sx;
+    if (gather == 1) {
+        sy = y * stride - pad + ky * dil;
+        sx = x * stride - pad + kx * dil;
+        if ((unsigned)sy >= (unsigned)hs || (unsigned)sx >= (unsigned)ws) return -1;
+    } else {
+        sy = y + pad - ky * dil;
+        sx = x + pad - kx * dil;
+        if (sy < 0 || sx < 0) return -1;
+        if (stride > 1) {
+            if ((sy % stride) != 0 || (sx % stride) != 0) return -1;
+            sy /= stride; sx /= stride;
+        }
+        if (sy >= hs || sx >= ws) return -1;
+    }
+    return (n * hs + sy) * ws + sx;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
+    if (nvalid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+    return v;
+}
+
+// Rectangle of destination pixels for which `tap` reads inside the source map (stride 1 only):
+//   gather 1: 0 <= y - pad + ky*dil < hs ;  gather 2: 0 <= y + pad - ky*dil < hs.
+// ASPP's rate-12/24 3x3 convs on a 28x28 map spend most taps in the padding (in-bounds fractions 51 % / 18 %);
+// in rect mode every tap becomes its own GEMM over exactly its rectangle (rows enumerate the rectangle, no
+// padding work at all) and the per-tap results are summed with float atomics into a zero-filled output.
+__host__ __device__ inline void tap_rect(int gather, int tap, int kw, int pad, int dil, int hs, int ws, int hd, int wd,
+                                         int& y0, int& y1, int& x0, int& x1) {
+    const int ky = tap / kw, kx = tap - ky * kw;
+    const int oy = (gather == 1) ? pad - ky * dil : ky * dil - pad;
+    const int ox = (gather == 1) ? pad - kx * dil : kx * dil - pad;
+    y0 = oy > 0 ? oy : 0;           y1 = hs + oy < hd ? hs + oy : hd;
+    x0 = ox > 0 ? ox : 0;           x1 = ws + ox < wd ? ws + ox : wd;
+    if (y1 < y0) y1 = y0;
+    if (x1 < x0) x1 = x0;
+}
+
+// value select (a `cond ? reg4 : make_float4(0.f, 0.f, 0.f, 0.f)` on two lvalues becomes a pointer select through scratch)
+__device__ __forceinline__ float4 keep_if(bool c, const float4 v) {
+    return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+int validate(const glf_gemm_params* p, const void* A, const void* B, const void* C) {
+    GLF_REQUIRE(p && A && B && C, GLF_ERR_NULL, "gemm: null argument");
+    GLF_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, GLF_ERR_BAD_SHAPE, "gemm: M,N,K must be > 0 (got %d,%d,%d)", p->M, p->N, p->K);
+    GLF_REQUIRE(p->taps >= 1 && p->taps <= 32, GLF_ERR_BAD_SHAPE, "gemm: taps must be in [1,32] (got %d)", p->taps);
+    GLF_REQUIRE(p->batch >= 1 && p->batch <= 65535, GLF_ERR_BAD_SHAPE, "gemm: batch out of range (%d)", p->batch);
+    GLF_REQUIRE(p->gather >= 0 && p->gather <= 2, GLF_ERR_BAD_SHAPE, "gemm: gather must be 0,1,2");
+    const unsigned full = p->taps == 32 ? 0xffffffffu : ((1u << p->taps) - 1u);
+    GLF_REQUIRE((p->tap_mask & ~full) == 0, GLF_ERR_BAD_SHAPE, "gemm: tap_mask has bits beyond taps");
+    if (p->gather) {
+        GLF_REQUIRE(p->kh * p->kw == p->taps, GLF_ERR_BAD_SHAPE, "gemm: kh*kw != taps");
+        GLF_REQUIRE(p->stride >= 1 && p->dil >= 1 && p->hs > 0 && p->ws > 0 && p->hd > 0 && p->wd > 0 && p->n_img > 0,
+                    GLF_ERR_BAD_SHAPE, "gemm: bad conv geometry");
+    } else {
+        GLF_REQUIRE(p->taps == 1, GLF_ERR_BAD_SHAPE, "gemm: taps > 1 needs a gather mapping");
+    }
+    return GLF_OK;
+}
+
+GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, const glf_gemm_params* p) {
+    GemmArgs a;
+    a.A = A; a.B = B; a.bias = bias; a.C = C;
+    a.M = p->M; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc; a.taps = p->taps;
+    a.tap_mask = p->tap_mask; a.tap_stride_b = p->tap_stride_b; a.gather = p->gather;
+    a.g = Geo{p->n_img, p->hs, p->ws, p->hd, p->wd, p->kh, p->kw, p->stride, p->pad, p->dil};
+    a.bsa = p->batch_stride_a; a.bsb = p->batch_stride_b; a.bsc = p->batch_stride_c;
+    a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
+    a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
+    a.vec_a = 0; a.vec_b = 0; a.rect = 0;
+    return a;
+}
+
+// rect mode (tap-parallel rectangles): validates and sizes the grid as the sum over taps of their tiles
+int setup_rect(const glf_gemm_params* p, const float* bias, GemmArgs& a, dim3& grid, const char* who) {
+    GLF_REQUIRE(p->gather == 1 || p->gather == 2, GLF_ERR_BAD_SHAPE, "%s: rect mode needs a conv gather", who);
+    GLF_REQUIRE(p->stride == 1, GLF_ERR_UNSUPPORTED, "%s: rect mode needs stride 1", who);
+    GLF_REQUIRE(bias == nullptr && !p->accumulate && p->batch == 1, GLF_ERR_UNSUPPORTED,
+                "%s: rect mode takes no bias / accumulate / batch (C must be zero-filled by the caller)", who);
+    long long tiles = 0;
+    for (unsigned mm = p->tap_mask; mm; mm &= mm - 1) {
+        const int t = __builtin_ctz(mm);
+        int y0, y1, x0, x1;
+        tap_rect(p->gather, t, p->kw, p->pad, p->dil, p->hs, p->ws, p->hd, p->wd, y0, y1, x0, x1);
+        const long long mt = (long long)p->n_img * (y1 - y0) * (x1 - x0);
+        tiles += (mt + BM - 1) / BM;
+    }
+    GLF_REQUIRE(tiles > 0 && tiles * a.tiles_n < 2147483647LL, GLF_ERR_BAD_SHAPE, "%s: rect mode grid out of range", who);
+    a.rect = 1;
+    grid = dim3((unsigned)(tiles * a.tiles_n), 1, 1);
+    return GLF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+
+}  // namespace
