@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
+    ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("GLF_PRECISION", "f32"),
+                    help="contraction kernels: exact fp32 MFMA, or split-bf16 (six bf16 MFMAs per product, fp32-equivalent)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,6 +119,7 @@ def main():
 
     from glfusion_amd import ops
     from glfusion_amd.ddp import GradAllReducer
+    ops.set_precision(args.precision)
 
     n_frames = args.clips * T
     model = build_model(dev)

@@ -2,15 +2,7 @@
 #pragma once
 #include "glf_common.h"
 
-namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LD_T = 129;   // LDS row stride of a tile filled by the transposing scatter
-constexpr int LD_V = 132;   // LDS row stride of a tile filled with ds_write_b128
-constexpr int NTHREADS = 256;
-
+namespace glf {
 struct Geo { int n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil; };
 
 struct GemmArgs {
@@ -27,6 +19,26 @@ struct GemmArgs {
     int vec_a, vec_b;
     int rect;       // tap-parallel rectangle mode (see tap_rect)
 };
+
+
+int precision();                               // 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x6); glf_api.hip
+int init_gemm_bf16s_attrs();                   // gemm_bf16s.hip
+bool bf16s_rows_ok(const GemmArgs& a);
+bool bf16s_tn_ok(const GemmArgs& a);
+int launch_rows_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+int launch_tn_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+}  // namespace glf
+
+namespace {
+using glf::Geo;
+using glf::GemmArgs;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_T = 129;   // LDS row stride of a tile filled by the transposing scatter
+constexpr int LD_V = 132;   // LDS row stride of a tile filled with ds_write_b128
+constexpr int NTHREADS = 256;
 
 // Scalar copy of the conv geometry: kernels keep it (and every other GemmArgs field they use) in local
 // scalars -- lambdas that capture the by-value kernel argument struct by reference made hipcc spill the whole

@@ -603,7 +603,7 @@ int init_gemm_attrs() {
     SET_ATTR((gemm_tn_kernel<false>), SMEM_TN)
     SET_ATTR((gemm_tn_kernel<true>), SMEM_TN)
 #undef SET_ATTR
-    return GLF_OK;
+    return init_gemm_bf16s_attrs();
 }
 }  // namespace glf
 
@@ -621,6 +621,7 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
+    if (glf::precision() == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
     if (p->gather)
         hipLaunchKernelGGL((gemm_rows_kernel<0, true>), grid, dim3(NTHREADS), SMEM_ROWS_NT, glf::S(stream), a);
     else
@@ -668,6 +669,7 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
         a.rect = 1;
     }
     dim3 grid(a.tiles_m * a.tiles_n, ntap, p->batch * a.split);
+    if (glf::precision() == 1 && glf::bf16s_tn_ok(a)) return glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
     if (p->gather)
         hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
     else

@@ -21,6 +21,9 @@ int fail(int code, const char* fmt, ...) {
 }
 
 static std::atomic<int> g_cus{0};
+static std::atomic<int> g_precision{0};
+
+int precision() { return g_precision.load(std::memory_order_relaxed); }
 static std::once_flag g_once;
 static int g_init_rc = GLF_OK;
 
@@ -49,3 +52,9 @@ extern "C" const char* glf_last_error(void) { return glf::err_buf(); }
 extern "C" int glf_abi_version(void) { return 2; }
 extern "C" int glf_init(void) { return glf::ensure_init(); }
 extern "C" size_t glf_sizeof_gemm_params(void) { return sizeof(glf_gemm_params); }
+extern "C" int glf_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return glf::fail(GLF_ERR_UNSUPPORTED, "glf_set_precision: mode must be 0 (fp32 MFMA) or 1 (split-bf16 x6)");
+    glf::g_precision.store(mode);
+    return GLF_OK;
+}
+extern "C" int glf_get_precision(void) { return glf::precision(); }

@@ -42,6 +42,32 @@ __global__ void tap_to_oihw_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
+// out[t][ci][co] = w[co][ci][t]  (the dgrad operand of the split-bf16 path: k = co contiguous)
+__global__ void oihw_to_tap_t_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps) {
+    const long long total = (long long)cout * cin * taps;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(o % cout); long long r = o / cout;
+        const int ci = (int)(r % cin); const int t = (int)(r / cin);
+        out[o] = w[((long long)co * cin + ci) * taps + t];
+    }
+}
+// batched 2-D transpose through a padded 32x32 LDS tile: dst[b][c][r] = src[b][r][c]
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const long long boff = (long long)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[boff + (long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[boff + (long long)c * rows + r] = tile[tx][i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // stem 7x7, Cin = 1.  One workgroup = 16x16 output pixels; the 22x22 input patch and the
 // 49 x Cout weights sit in LDS; each thread owns one pixel x 16 output channels per pass.
@@ -473,6 +499,21 @@ extern "C" int glf_tap_major_to_oihw(const float* w, float* out, int cout, int c
     const long long cc = (long long)cout * cin;
     hipLaunchKernelGGL(tap_to_oihw_kernel, dim3(stream_grid(cc * taps, 256)), dim3(256), 0, glf::S(s), w, out, cc, taps);
     return glf::check_launch("tap_major_to_oihw");
+}
+
+extern "C" int glf_oihw_to_tap_major_t(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(w && out, GLF_ERR_NULL, "oihw_to_tap_major_t: null argument");
+    GLF_REQUIRE(cout > 0 && cin > 0 && taps > 0, GLF_ERR_BAD_SHAPE, "oihw_to_tap_major_t: bad shape");
+    hipLaunchKernelGGL(oihw_to_tap_t_kernel, dim3(stream_grid((long long)cout * cin * taps, 256)), dim3(256), 0, glf::S(s), w, out, cout, cin, taps);
+    return glf::check_launch("oihw_to_tap_major_t");
+}
+extern "C" int glf_transpose2d(const float* src, float* dst, int rows, int cols, int batch, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(src && dst, GLF_ERR_NULL, "transpose2d: null argument");
+    GLF_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && (rows + 31) / 32 <= 65535, GLF_ERR_BAD_SHAPE, "transpose2d: bad shape");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, glf::S(s), src, dst, rows, cols);
+    return glf::check_launch("transpose2d");
 }
 
 extern "C" int glf_stem7x7_fwd(const float* x, const float* w, const float* bias, float* y,

@@ -20,7 +20,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import check, lib
-from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, colsum, gemm
+from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, colsum, gemm, split_mode, transpose2d, weight_T
 
 
 class TpaviFn(Function):
@@ -50,7 +50,12 @@ class TpaviFn(Function):
             att = torch.empty(n, ci, ci, **f32)                              # M_n = phi_n^T g_n / L
             gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=L * ci,
                  bsc=ci * ci, alpha=1.0 / L)
-            gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
+            if split_mode() and ci % 32 == 0:      # y_n = theta_n M_n as NT against M_n^T (split-bf16 kernels are NT / TN only)
+                attT = transpose2d(att, ci, ci, n)
+                gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
+                del attT
+            else:
+                gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
         elif mode == "embedded":
             att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T)
             gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=ci, ldb=ci, ldc=L, batch=n, bsa=L * ci, bsb=L * ci, bsc=L * L)
@@ -76,6 +81,7 @@ class TpaviFn(Function):
                                     _p(z), _p(rmu), _p(rrs), rows, c, _stream()), "bn_res_ln_fwd")
         ctx.save_for_backward(x, th, ph, g, att, y, wz, mean, invstd, rmu, rrs, thW, phW, gW, zW, bn_g, bn_b, ln_g)
         ctx.cfg = (n, L, c, ci, training, mode, tuple(th_w.shape), tuple(wz_w.shape))
+        ctx.owners = (th_w, ph_w, g_w, wz_w)      # parameters owning thW/phW/gW/zW (transposed-copy cache keys)
         return z
 
     @staticmethod
@@ -105,8 +111,13 @@ class TpaviFn(Function):
         dzW = (torch.empty if sp == 1 else torch.zeros)(c, ci, **f32)
         gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp)
         dzb = colsum(dwz, rows, c)
+        split = split_mode() and ci % 32 == 0 and c % 32 == 0
+        th_o, ph_o, g_o, wz_o = ctx.owners
         dy = torch.empty(rows, ci, **f32)
-        gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
+        if split:
+            gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci)
+        else:
+            gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
         del dwz
 
         dth = torch.empty(rows, ci, **f32)
@@ -119,7 +130,12 @@ class TpaviFn(Function):
             dM = torch.empty(n, ci, ci, **f32)
             gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=bs, bsc=ci * ci)
             gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
-            gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+            if split:
+                dMT = transpose2d(dM, ci, ci, n)
+                gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+                del dMT
+            else:
+                gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
         else:
             # y_n = P_n g_n ; P_n = softmax(th_n ph_n^T)
             dP = torch.empty(n, L, L, **f32)
@@ -135,12 +151,15 @@ class TpaviFn(Function):
         sp = _tn_split(rows, ci, c, 1)
         grads_w, grads_b = [], []
         dx = du                                              # residual gradient, accumulated in place
-        for d, Wm in ((dth, thW), (dph, phW), (dg, gW)):
+        for d, Wm, owner in ((dth, thW, th_o), (dph, phW, ph_o), (dg, gW, g_o)):
             dW = (torch.empty if sp == 1 else torch.zeros)(ci, c, **f32)
             gemm("tn", d, x, dW, M=ci, N=c, K=rows, lda=ci, ldb=c, ldc=c, split=sp)
             grads_w.append(dW.view(pshape))
             grads_b.append(colsum(d, rows, ci))
-            gemm("nn", d, Wm, dx, M=rows, N=c, K=ci, lda=ci, ldb=c, ldc=c, accumulate=True)
+            if split:
+                gemm("nt", d, weight_T(Wm, owner), dx, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, accumulate=True)
+            else:
+                gemm("nn", d, Wm, dx, M=rows, N=c, K=ci, lda=ci, ldb=c, ldc=c, accumulate=True)
         dx = dx.view_as(x)
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], dzW.view(zshape), dzb,
                 dbn_g, dbn_b, dln_g, dln_b, None, None, None, None, None, None, None, None)

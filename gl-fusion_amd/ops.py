@@ -170,6 +170,46 @@ def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
     return db
 
 
+def split_mode() -> bool:
+    """True when contractions run on the split-bf16 (bf16x6) kernels."""
+    return int(lib.glf_get_precision()) == 1
+
+
+def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.Tensor:
+    """[batch][rows][cols] -> [batch][cols][rows] (fresh tensor)."""
+    out = torch.empty(batch * rows * cols, dtype=torch.float32, device=x.device)
+    check(lib.glf_transpose2d(_p(x), _p(out), rows, cols, batch, _stream()), "transpose2d")
+    return out
+
+
+_wT_cache = {}
+
+
+def weight_T(w2d: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
+    """Transposed copy [cols][rows] of a 2-D weight view, cached against the owning parameter's version."""
+    rows, cols = w2d.shape
+    key = (id(owner), "T2")
+    hit = _wT_cache.get(key)
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[3] == owner.data_ptr():
+        return hit[2]
+    wt = transpose2d(_contig(w2d), rows, cols).view(cols, rows)
+    _wT_cache[key] = (weakref.ref(owner, lambda _r, k=key: _wT_cache.pop(k, None)), owner._version, wt, owner.data_ptr())
+    return wt
+
+
+def tap_major_T(weight: torch.Tensor) -> torch.Tensor:
+    """[tap][Cin][Cout] re-layout (dgrad as an NT contraction), cached like tap_major."""
+    co, ci, kh, kw = weight.shape
+    key = (id(weight), "tapT")
+    hit = _wT_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[3] == weight.data_ptr():
+        return hit[2]
+    wt = torch.empty(kh * kw, ci, co, dtype=torch.float32, device=weight.device)
+    check(lib.glf_oihw_to_tap_major_t(_p(_contig(weight.detach())), _p(wt), co, ci, kh * kw, _stream()), "oihw_to_tap_major_t")
+    _wT_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wT_cache.pop(k, None)), weight._version, wt, weight.data_ptr())
+    return wt
+
+
 # weight re-layout cache: OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes.
 # Entries are validated by object identity through a weak reference (id() and data_ptr() of a freed
 # parameter can both be reused by a new one) plus the in-place version counter.
@@ -252,6 +292,7 @@ class Conv2dFn(Function):
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect)
         ctx.save_for_backward(x, wt)
+        ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
         return y
 
@@ -272,9 +313,15 @@ class Conv2dFn(Function):
                 rect = (not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1
                         and rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
                 dx = torch.zeros_like(x) if rect else torch.empty_like(x)
-                gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
-                     tap_stride_b=cout * cin, gather=0 if plain else 2,
-                     geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
+                if split_mode() and cout % 32 == 0:
+                    # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
+                    gemm("nt", dy, tap_major_T(ctx.weight_ref), dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
+                         taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
+                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
+                else:
+                    gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+                         tap_stride_b=cout * cin, gather=0 if plain else 2,
+                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
         if ctx.needs_input_grad[1]:
             mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
             ntap = bin(mask).count("1")
@@ -322,6 +369,7 @@ class ConvCatFn(Function):
             raise RuntimeError(f"conv_cat: inputs have {off} channels in total, weight expects {ctot}")
         ctx.save_for_backward(w2, *xs)
         ctx.wshape = tuple(weight.shape)
+        ctx.weight_ref = weight
         return y
 
     @staticmethod
@@ -341,7 +389,11 @@ class ConvCatFn(Function):
             ck = t.shape[-1]
             if ctx.needs_input_grad[1 + i]:
                 dx = torch.empty_like(t)
-                gemm("nn", dy, w2[:, off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=ctot, ldc=ck)
+                if split_mode() and cout % 32 == 0:
+                    wT = weight_T(w2, ctx.weight_ref)                     # [ctot][cout]
+                    gemm("nt", dy, wT[off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=cout, ldc=ck)
+                else:
+                    gemm("nn", dy, w2[:, off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=ctot, ldc=ck)
                 grads.append(dx)
             else:
                 grads.append(None)
@@ -764,3 +816,14 @@ def overlap_metrics_from_counts(counts: torch.Tensor, eps: float = 1e-5):
     tp, fp, fn, tn = [float(v) for v in counts.tolist()]
     return ((tp + tn) / (tp + tn + fp + fn + eps), (2 * tp) / (2 * tp + fp + fn + eps),
             tp / (tp + fp + eps), tn / (tn + fp + eps), tp / (tp + fn + eps))
+
+
+# ----------------------------------------------------------------------------------------
+# contraction precision (process-wide): "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 emulation
+# ----------------------------------------------------------------------------------------
+def set_precision(mode: str) -> None:
+    check(lib.glf_set_precision({"f32": 0, "bf16x6": 1}[mode]), "set_precision")
+
+
+def get_precision() -> str:
+    return ("f32", "bf16x6")[int(lib.glf_get_precision())]

@@ -45,6 +45,14 @@ int glf_abi_version(void);
 /* Queries the current device once (CU count) and raises the dynamic-LDS limit of the MFMA
  * kernels.  Optional: every entry point calls it lazily. */
 int glf_init(void);
+/* Contraction precision of glf_gemm_nt / glf_gemm_tn (process-wide):
+ *   0 = exact fp32 on v_mfma_f32_32x32x2_f32 (default);
+ *   1 = split-bf16 "bf16x6": each fp32 operand is split into three bf16 pieces and six
+ *       v_mfma_f32_32x32x16_bf16 reproduce the fp32 product to 2^-23 (fp32 accumulate) -- fp32-equivalent
+ *       results at 2.67x the fp32-MFMA roof.  Calls that miss the aligned fast path (and glf_gemm_nn) stay
+ *       on the exact kernels. */
+int glf_set_precision(int mode);
+int glf_get_precision(void);
 /* sizeof(glf_gemm_params) as compiled into the library (binding self-check). */
 size_t glf_sizeof_gemm_params(void);
 
@@ -106,6 +114,10 @@ int glf_gemm_tn(const float* A, const float* B, float* C,
  * ------------------------------------------------------------------------------------- */
 int glf_oihw_to_tap_major(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
 int glf_tap_major_to_oihw(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
+/* [kh*kw][Cin][Cout] (k = Cout contiguous): the dgrad weight operand when dgrad runs as an NT contraction. */
+int glf_oihw_to_tap_major_t(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
+/* batched 2-D transpose dst[b][c][r] = src[b][r][c] (operand re-layout for NT contractions). */
+int glf_transpose2d(const float* src, float* dst, int rows, int cols, int batch, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Stem (a2): Conv2d(1,64,7,stride 1,pad 2)+bias (models/_utils.py:192; used ours.py:1796).

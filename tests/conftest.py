@@ -27,3 +27,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["f32", "bf16x6"])
+def precision(request):
+    """Runs a GPU test under both contraction precisions: exact fp32 MFMA and split-bf16 (bf16x6)."""
+    from glfusion_amd import ops
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision("f32")

@@ -61,7 +61,7 @@ def load_like(dst: torch.nn.Module, src: torch.nn.Module):
 
 
 @pytest.mark.parametrize("mode", ["dot", "embedded"])
-def test_tpavi_vs_golden(golden_dir, mode):
+def test_tpavi_vs_golden(golden_dir, mode, precision):
     from glfusion_amd.models import TPAVIModule
     g = np.load(os.path.join(golden_dir, f"tpavi_{mode}.npz"))
     m = TPAVIModule(64, mode=mode)
@@ -93,7 +93,7 @@ def test_tpavi_vs_golden(golden_dir, mode):
         assert close(m(x.detach())[0], g["z_eval"], 2e-5)
 
 
-def test_deeplab_head_vs_golden(golden_dir):
+def test_deeplab_head_vs_golden(golden_dir, precision):
     """Forward vs the reference's golden output; gradients are judged against an fp64 evaluation of the
     oracle, sized by the CPU fp32 oracle's own noise (the pooled ASPP branch normalises over N = 4
     samples per channel, which is ill-conditioned for ANY fp32 implementation)."""
@@ -130,7 +130,7 @@ def test_deeplab_head_vs_golden(golden_dir):
         assert close(head2(x.detach()), g["y_eval"], 2e-5)
 
 
-def test_bottleneck_stage_vs_oracle():
+def test_bottleneck_stage_vs_oracle(precision):
     """a3 (parity unpinned by the reference): the HIP stage against the oracle's restatement, layer2
     (stride-2 block + downsample) and the dilated layer4, train mode fwd + bwd; judged against the
     oracle in fp64, sized by the fp32 oracle's own noise."""
@@ -158,7 +158,7 @@ def test_bottleneck_stage_vs_oracle():
 
 
 @pytest.mark.parametrize("tag,views,n", [("c2", ["1", "3", "4"], 2), ("c1", ["1"], 8)])
-def test_e2e_eval_vs_golden(golden_dir, tag, views, n):
+def test_e2e_eval_vs_golden(golden_dir, tag, views, n, precision):
     """Eval-mode forward of the full model vs the reference's own outputs: logits within 1e-4, mask
     bits may differ only where |logit| < 1e-4, Dice within 1e-4."""
     from glfusion_amd import ops
@@ -189,7 +189,7 @@ def test_e2e_eval_vs_golden(golden_dir, tag, views, n):
             assert close(f.contiguous().reshape(-1)[idx], g[f"{nm}_val:{v}"], 1e-3), (nm, v)
 
 
-def test_e2e_train_step_vs_golden(golden_dir):
+def test_e2e_train_step_vs_golden(golden_dir, precision):
     """forward -> sum_v BCE-sum -> backward in train() (Dropout p = 0) vs the reference's step."""
     from glfusion_amd import ops
     from glfusion_amd.models import Global_and_Local

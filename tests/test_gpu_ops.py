@@ -25,9 +25,10 @@ def close(a, b, tol):
     return ok
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture
+def ops(precision):
     from glfusion_amd import ops as _ops
+    assert _ops.get_precision() == precision
     return _ops
 
 
