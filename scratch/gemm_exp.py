@@ -3,6 +3,7 @@ import glfusion_amd._lib as L
 if len(sys.argv)>1: L.LIB_PATH=os.path.join(os.path.dirname(L.LIB_PATH), sys.argv[1])
 import torch
 from glfusion_amd import ops
+ops.set_precision(sys.argv[2] if len(sys.argv)>2 else 'f32')
 DEV='cuda'
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
