@@ -34,6 +34,7 @@ import torch.distributed as dist
 VIEWS = ["1", "3", "4"]
 B, T, H, W = 4, 16, 112, 112
 FP32_MFMA_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
 DENSE_GFLOP_PER_FRAME_FWD = 531.57      # 2 x 265.786 GMAC, all 3 views, per frame
 
 
@@ -100,8 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
-    ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("GLF_PRECISION", "f32"),
-                    help="contraction kernels: exact fp32 MFMA, or split-bf16 (six bf16 MFMAs per product, fp32-equivalent)")
+    ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("GLF_PRECISION", "bf16x6"),
+                    help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
+                         "passes the same parity gates; default) or f32 = exact v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,25 +191,35 @@ def main():
             a[3] += 1
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         name, (secs, dense, kept, launches) = dom
-        achieved = dense / secs / 1e12
         all_secs = sum(a[0] for a in agg.values())
         all_dense = sum(a[1] for a in agg.values())
+        split = args.precision == "bf16x6"
+        # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
+        # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
+        #         bf16 FLOPs / time against the dense bf16 MFMA peak; the fp32-equivalent rates are given beside it
+        if split:
+            achieved, peak = 6.0 * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
+            kname = name.replace("gemm_rows_kernel<0,", "gemm_rows_bf16s8_kernel<").replace("gemm_tn_kernel<", "gemm_tn_bf16s_kernel<")
+        else:
+            achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
         roofline = {
-            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "arithmetic": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate" if split
+                          else "v_mfma_f32_32x32x2_f32 (exact fp32)",
             "launches_per_step": launches // args.steps, "avg_launch_ms": round(secs / launches * 1e3, 4),
-            "executed_tflops": round(kept / secs / 1e12, 2),
-            "all_contractions": {"achieved": round(all_dense / all_secs / 1e12, 2), "share_of_step": round(all_secs / dt, 4),
+            "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
+            "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2), "share_of_step": round(all_secs / dt, 4),
                                  "per_kernel_s_per_step": {k: round(a[0] / args.steps, 4) for k, a in sorted(agg.items())}},
-            "whole_step_dense": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
+            "whole_step_dense_tflops": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
         }
         out = {
             "metric": "clips/sec fwd+bwd (B=4, 3 views x16x112x112) per GPU, weak scaling", "value": round(value, 4),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
-                       "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames,
+                       "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
             "loss": loss_val, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
             "roofline": roofline,
