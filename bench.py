@@ -113,11 +113,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        if os.environ.get("GLF_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        local_rank = 0                                             # rehearsal: several ranks share the one GPU over gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GLF_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from glfusion_amd import ops
     from glfusion_amd.ddp import GradAllReducer

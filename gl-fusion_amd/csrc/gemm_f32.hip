@@ -676,3 +676,4 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
         hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
     return glf::check_launch("gemm_tn");
 }
+
