@@ -13,9 +13,15 @@ namespace {
 constexpr int RT = 256;               // threads of a reduction workgroup
 constexpr int MAX_SLICES = 1024;
 
-__host__ __device__ inline int n_slices(int rows) {
+// row slices of the stage-1 grid: enough workgroups to stream at the HBM rate (grid = slices x channel blocks of
+// up to 1024 channels) while the f64 partials stay small (2 x slices x C x 8 B; 33 MB per BatchNorm at C = 2048 with
+// 1024 slices made the stage-2 kernels 2 % of the step)
+__host__ __device__ inline int n_slices_c(int rows, int c) {
     int s = (rows + 31) / 32;
-    return s < 1 ? 1 : (s > MAX_SLICES ? MAX_SLICES : s);
+    int cap = 524288 / (c > 0 ? c : 1);
+    if (cap < 128) cap = 128;
+    if (cap > MAX_SLICES) cap = MAX_SLICES;
+    return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
 struct Coef { const float* mean; const float* invstd; const float* gamma; const float* beta; };
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(RT) void colreduce_kernel(Op op, int rows, int c, i
     const int slice = blockIdx.x;
     const int per = (rows + slices - 1) / slices;
     const int r0 = slice * per, r1 = min(rows, r0 + per);
-    for (int cb = 0; cb < c4; cb += tpr) {
+    for (int cb = blockIdx.y * tpr; cb < c4; cb += gridDim.y * tpr) {
         const int cc = cb + ct;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (cc < c4 && rl < rpp) {
@@ -336,15 +342,16 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 
 template <class Op>
 int launch_colreduce(Op op, int rows, int c, double* ws, hipStream_t s) {
-    const int slices = n_slices(rows);
-    hipLaunchKernelGGL((colreduce_kernel<Op>), dim3(slices), dim3(RT), 0, s, op, rows, c, slices, ws);
+    const int slices = n_slices_c(rows, c);
+    const int c4 = c / 4, tpr = c4 < RT ? c4 : RT;
+    hipLaunchKernelGGL((colreduce_kernel<Op>), dim3(slices, (c4 + tpr - 1) / tpr), dim3(RT), 0, s, op, rows, c, slices, ws);
     return glf::check_launch("colreduce");
 }
 
 }  // namespace
 
 extern "C" size_t glf_bn_workspace(int rows, int c) {
-    return (size_t)2 * n_slices(rows) * (size_t)(c > 0 ? c : 0) + (size_t)2 * (c > 0 ? c : 0);
+    return (size_t)2 * MAX_SLICES * (size_t)(c > 0 ? c : 0) + (size_t)2 * (c > 0 ? c : 0);
 }
 
 #define REQ_C4(c) GLF_REQUIRE((c) > 0 && ((c) % 4) == 0, GLF_ERR_BAD_SHAPE, "channel count must be a positive multiple of 4 (got %d)", (c))
@@ -360,7 +367,7 @@ extern "C" int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps,
     REQ_C4(c); REQ_AL(x, "x"); REQ_LD(ldx, "ldx");
     GLF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GLF_ERR_NULL, "bn_stats: running_mean/var must both be set or both NULL");
     if (int rc = launch_colreduce(OpStats{x, ldx}, rows, c, workspace, glf::S(s))) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, rows,
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices_c(rows, c), c, rows,
                        eps, momentum, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
     return glf::check_launch("bn_stats_finalize");
 }
@@ -397,7 +404,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
     if (relu) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
-    const int slices = n_slices(rows);
+    const int slices = n_slices_c(rows, c);
     if (int rc = launch_colreduce(OpBnBwd{dy, lddy, x, ldx, y, ldy, mean, invstd, relu}, rows, c, workspace, glf::S(s))) return rc;
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
@@ -418,7 +425,7 @@ extern "C" int glf_colsum(const float* dy, int lddy, float* db, int rows, int c,
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "colsum: rows must be > 0");
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_LD(lddy, "lddy");
     if (int rc = launch_colreduce(OpColsum{dy, lddy}, rows, c, workspace, glf::S(s))) return rc;
-    hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, db, (float*)nullptr);
+    hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices_c(rows, c), c, db, (float*)nullptr);
     return glf::check_launch("colsum_finalize");
 }
 
@@ -455,6 +462,6 @@ extern "C" int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x
                        dz, du, rows, c);
     if (int rc = glf::check_launch("bn_res_ln_bwd")) return rc;
     if (int rc = launch_colreduce(OpLnParam{dz, w, x, bn, row_mean, row_rstd, c}, rows, c, workspace, glf::S(s))) return rc;
-    hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices(rows), c, dln_gamma, dln_beta);
+    hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices_c(rows, c), c, dln_gamma, dln_beta);
     return glf::check_launch("ln_param_finalize");
 }

@@ -39,28 +39,32 @@ class TpaviFn(Function):
         W = lambda t: _contig(t.detach()).view(t.shape[0], t.shape[1])       # Conv3d 1x1x1 weight -> [out, in]
         thW, phW, gW, zW = W(th_w), W(ph_w), W(g_w), W(wz_w)
 
-        th = torch.empty(rows, ci, **f32)
-        ph = torch.empty(rows, ci, **f32)
-        g = torch.empty(rows, ci, **f32)
-        for out, wt, b in ((th, thW, th_b), (ph, phW, ph_b), (g, gW, g_b)):
-            gemm("nt", x, wt, out, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, bias=b)
+        # theta | phi | g in ONE contraction over the shared input: qkv[rows, 3*ci] (x is read once; the three
+        # operands below are column slices with row stride 3*ci)
+        Wcat = torch.cat((thW, phW, gW), dim=0)                              # [3*ci, c]
+        bcat = torch.cat((th_b.detach(), ph_b.detach(), g_b.detach()), dim=0)
+        c3 = 3 * ci
+        qkv = torch.empty(rows, c3, **f32)
+        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat)
+        th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
+        bq = L * c3                                                          # batch (frame) stride inside qkv
 
         y = torch.empty(rows, ci, **f32)
         if mode == "dot":
             att = torch.empty(n, ci, ci, **f32)                              # M_n = phi_n^T g_n / L
-            gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=L * ci,
+            gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=c3, ldb=c3, ldc=ci, batch=n, bsa=bq, bsb=bq,
                  bsc=ci * ci, alpha=1.0 / L)
             if split_mode() and ci % 32 == 0:      # y_n = theta_n M_n as NT against M_n^T (split-bf16 kernels are NT / TN only)
                 attT = transpose2d(att, ci, ci, n)
-                gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
+                gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
                 del attT
             else:
-                gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=L * ci, bsb=ci * ci, bsc=L * ci)
+                gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
         elif mode == "embedded":
             att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T)
-            gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=ci, ldb=ci, ldc=L, batch=n, bsa=L * ci, bsb=L * ci, bsc=L * L)
+            gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=c3, ldb=c3, ldc=L, batch=n, bsa=bq, bsb=bq, bsc=L * L)
             check(lib.glf_softmax_rows(_p(att), n * L, L, _stream()), "softmax_rows")
-            gemm("nn", att, g, y, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=L * ci, bsc=L * ci)
+            gemm("nn", att, g, y, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=ci, batch=n, bsa=L * L, bsb=bq, bsc=L * ci)
         else:
             raise RuntimeError(f"TPAVI mode {mode!r} is not on the path (built: 'dot', 'embedded')")
 
@@ -79,20 +83,23 @@ class TpaviFn(Function):
         rrs = torch.empty(rows, **f32)
         check(lib.glf_bn_res_ln_fwd(_p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(ln_b), ln_eps,
                                     _p(z), _p(rmu), _p(rrs), rows, c, _stream()), "bn_res_ln_fwd")
-        ctx.save_for_backward(x, th, ph, g, att, y, wz, mean, invstd, rmu, rrs, thW, phW, gW, zW, bn_g, bn_b, ln_g)
+        ctx.save_for_backward(x, qkv, att, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g)
         ctx.cfg = (n, L, c, ci, training, mode, tuple(th_w.shape), tuple(wz_w.shape))
-        ctx.owners = (th_w, ph_w, g_w, wz_w)      # parameters owning thW/phW/gW/zW (transposed-copy cache keys)
+        ctx.owners = (wz_w,)                      # parameter owning zW (transposed-copy cache key)
         return z
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz):
-        (x, th, ph, g, att, y, wz, mean, invstd, rmu, rrs, thW, phW, gW, zW, bn_g, bn_b, ln_g) = ctx.saved_tensors
+        (x, qkv, att, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g) = ctx.saved_tensors
         n, L, c, ci, training, mode, pshape, zshape = ctx.cfg
         rows = n * L
         dev = dz.device
         f32 = dict(dtype=torch.float32, device=dev)
         dz = _contig(dz)
+        c3 = 3 * ci
+        bq = L * c3
+        th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
 
         # LayerNorm backward -> du (gradient of u = BN(w) + x); it is also the residual's gradient
         du = torch.empty(rows, c, **f32)
@@ -112,7 +119,7 @@ class TpaviFn(Function):
         gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp)
         dzb = colsum(dwz, rows, c)
         split = split_mode() and ci % 32 == 0 and c % 32 == 0
-        th_o, ph_o, g_o, wz_o = ctx.owners
+        (wz_o,) = ctx.owners
         dy = torch.empty(rows, ci, **f32)
         if split:
             gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci)
@@ -120,46 +127,45 @@ class TpaviFn(Function):
             gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
         del dwz
 
-        dth = torch.empty(rows, ci, **f32)
-        dph = torch.empty(rows, ci, **f32)
-        dg = torch.empty(rows, ci, **f32)
+        dqkv = torch.empty(rows, c3, **f32)                   # [d theta | d phi | d g], row stride 3*ci
+        dth, dph, dg = dqkv[:, 0:ci], dqkv[:, ci:2 * ci], dqkv[:, 2 * ci:]
         bs = L * ci
         if mode == "dot":
             # y_n = th_n M_n ;  M_n = ph_n^T g_n / L
-            gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs)
+            gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=c3, batch=n, bsa=bs, bsb=ci * ci, bsc=bq)
             dM = torch.empty(n, ci, ci, **f32)
-            gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=bs, bsc=ci * ci)
-            gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+            gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=bs, bsc=ci * ci)
+            gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
             if split:
                 dMT = transpose2d(dM, ci, ci, n)
-                gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+                gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
                 del dMT
             else:
-                gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=ci, batch=n, bsa=bs, bsb=ci * ci, bsc=bs, alpha=1.0 / L)
+                gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
         else:
             # y_n = P_n g_n ; P_n = softmax(th_n ph_n^T)
             dP = torch.empty(n, L, L, **f32)
-            gemm("nt", dy, g, dP, M=L, N=L, K=ci, lda=ci, ldb=ci, ldc=L, batch=n, bsa=bs, bsb=bs, bsc=L * L)
-            gemm("tn", att, dy, dg, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
+            gemm("nt", dy, g, dP, M=L, N=L, K=ci, lda=ci, ldb=c3, ldc=L, batch=n, bsa=bs, bsb=bq, bsc=L * L)
+            gemm("tn", att, dy, dg, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=c3, batch=n, bsa=L * L, bsb=bs, bsc=bq)
             check(lib.glf_softmax_rows_bwd(_p(att), _p(dP), n * L, L, _stream()), "softmax_rows_bwd")   # dP <- dS
-            gemm("nn", dP, ph, dth, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
-            gemm("tn", dP, th, dph, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=ci, batch=n, bsa=L * L, bsb=bs, bsc=bs)
+            gemm("nn", dP, ph, dth, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=c3, batch=n, bsa=L * L, bsb=bq, bsc=bq)
+            gemm("tn", dP, th, dph, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=c3, batch=n, bsa=L * L, bsb=bq, bsc=bq)
             del dP
         del dy
 
-        # projections: out = x W^T + b
-        sp = _tn_split(rows, ci, c, 1)
-        grads_w, grads_b = [], []
-        dx = du                                              # residual gradient, accumulated in place
-        for d, Wm, owner in ((dth, thW, th_o), (dph, phW, ph_o), (dg, gW, g_o)):
-            dW = (torch.empty if sp == 1 else torch.zeros)(ci, c, **f32)
-            gemm("tn", d, x, dW, M=ci, N=c, K=rows, lda=ci, ldb=c, ldc=c, split=sp)
-            grads_w.append(dW.view(pshape))
-            grads_b.append(colsum(d, rows, ci))
-            if split:
-                gemm("nt", d, weight_T(Wm, owner), dx, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, accumulate=True)
-            else:
-                gemm("nn", d, Wm, dx, M=rows, N=c, K=ci, lda=ci, ldb=c, ldc=c, accumulate=True)
+        # the three projections as one: qkv = x Wcat^T + bcat
+        sp = _tn_split(rows, c3, c, 1)
+        dWcat = (torch.empty if sp == 1 else torch.zeros)(c3, c, **f32)
+        gemm("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp)
+        dbcat = colsum(dqkv, rows, c3)
+        grads_w = [dWcat[i * ci:(i + 1) * ci].reshape(pshape) for i in range(3)]
+        grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
+        dx = du                                              # residual gradient, accumulated in place (one RMW)
+        if split:
+            WcatT = transpose2d(Wcat, c3, c).view(c, c3)
+            gemm("nt", dqkv, WcatT, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True)
+        else:
+            gemm("nn", dqkv, Wcat, dx, M=rows, N=c, K=c3, lda=c3, ldb=c, ldc=c, accumulate=True)
         dx = dx.view_as(x)
         return (dx, grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], dzW.view(zshape), dzb,
                 dbn_g, dbn_b, dln_g, dln_b, None, None, None, None, None, None, None, None)
