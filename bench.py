@@ -55,6 +55,21 @@ def make_batch(dev, rank, n_frames):
     return imgs, tgts
 
 
+def pmc_traffic_per_launch(kernel: str, precision: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    profiles/summarize_pmc.py) -- PMC counters cannot be collected inside this process, so the figure is the one
+    measured on the same workload when the profile was taken; None if the profile is missing."""
+    path = os.path.join(ROOT, "profiles", f"r01_bench_c2_{precision}_pmc_hbm_traffic.csv")
+    try:
+        for line in open(path).read().splitlines()[1:]:
+            name, rest = line.rsplit(",", 5)[0], line.rsplit(",", 5)[1:]
+            if name.replace(" ", "") == kernel.replace(" ", ""):
+                return {"bytes_per_launch": float(rest[4]) * 1e6, "unit": "B", "source": os.path.relpath(path, ROOT)}
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def host_cores() -> int:
     """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -212,7 +227,7 @@ def main():
             achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic_per_launch(kname, args.precision),
             "arithmetic": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate" if split
                           else "v_mfma_f32_32x32x2_f32 (exact fp32)",
             "launches_per_step": launches // args.steps, "avg_launch_ms": round(secs / launches * 1e3, 4),

@@ -8,14 +8,13 @@
 // fp32 accuracy (measured vs fp64: same error as the exact-fp32 kernels, see tests/test_gpu_ops.py).
 //
 // Layout: operands are split while they are written to LDS (one fp32 global read, three bf16 planes in LDS).
-//   rows kernel (NT: A[m][k], B[n][k], both k-contiguous): planes [row][32 k] with 80-byte rows; a fragment
-//     (row = lane&31, k = 8*(lane>>5) .. +7) is ONE conflict-free ds_read_b128.
+//   rows kernel (NT: A[m][k], B[n][k], both k-contiguous): planes [row][32 k] with swizzled 64-byte rows; a
+//     fragment (row = lane&31, k = 8*(lane>>5) .. +7) is ONE conflict-free ds_read_b128.
 //   tn kernel (reduction over rows r: A[r][m], B[r][n]): planes [r][128 m] with 320-byte rows; fragments are
 //     transposed on the fly by ds_read_b64_tr_b16 (two per fragment), conflict-free for that stride.
 // Same gather / tap_mask / rect semantics, epilogues and XCD-aware tile order as gemm_f32.hip.  Only the aligned
 // fast path is built (K % 32 == 0, 16-byte aligned rows); everything else stays on the exact-fp32 kernels.
 #include "gemm_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -23,10 +22,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RS = 80;                   // bytes per LDS row of the rows kernel (32 bf16 + 16 B pad)
-constexpr int PLANE = 128 * RS;          // one bf16 plane of a 128-row operand tile
-constexpr int OPER = 3 * PLANE;          // hi, mid, lo
-constexpr size_t SMEM_ROWS_S = 2 * OPER + 16;
 constexpr int RST = 320;                 // bytes per LDS row of the tn kernel (128 bf16 + 64 B pad)
 constexpr int PLANE_T = 32 * RST;
 constexpr int OPER_T = 3 * PLANE_T;
@@ -86,223 +81,7 @@ __device__ __forceinline__ Split4 split4(const float4 v) {
     if ((s_) == 0) { GLF_SIX0(t, ah, am, al, bh, bm, bl) } else { GLF_SIX(t, ah, am, al, bh, bm, bl) }
 
 // ----------------------------------------------------------------------------------------------------------
-// rows kernel, NT: C[m][n] = alpha * sum_tap sum_k A[src(m,tap)][k] * B_tap[n][k] (+ bias)
-// ----------------------------------------------------------------------------------------------------------
-template <bool GATHER>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_bf16s_kernel(const GemmArgs args) {
-    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
-    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
-    const int p_tiles_n = args.tiles_n;
-    const unsigned p_tap_mask = args.tap_mask;
-    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
-    const float p_alpha = args.alpha;
-    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B; const float* __restrict__ p_bias = args.bias;
-    float* __restrict__ p_C = args.C;
-    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
-    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
-    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-    unsigned char* As = smem_s;
-    unsigned char* Bs = smem_s + OPER;
-    unsigned* s_mask = reinterpret_cast<unsigned*>(smem_s + 2 * OPER);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % p_tiles_n;
-    int tm = bid / p_tiles_n;
-    int pMe = pM;
-    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd;
-    unsigned mask = p_tap_mask;
-    if (p_rect) {
-        for (unsigned mm = p_tap_mask; mm; mm &= mm - 1) {
-            const int t = __ffs(mm) - 1;
-            int y0, y1, x0, x1;
-            tap_rect(p_gather, t, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
-            const int mt = g_nimg * (y1 - y0) * (x1 - x0);
-            const int tiles = (mt + BM - 1) / BM;
-            if (tm < tiles || (mm & (mm - 1)) == 0) { mask = 1u << t; pMe = mt; r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0; break; }
-            tm -= tiles;
-        }
-    }
-    const int bz = blockIdx.z;
-    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
-    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
-    float* __restrict__ C = p_C + (long long)bz * p_bsc;
-
-    const int ac = tid & 7, ar = tid >> 3;
-
-    int a_n[4], a_y[4], a_x[4];
-    long long a_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = tm * BM + ar + 32 * j;
-        if (GATHER) {
-            if (m < pMe) {
-                const int hw = r_h * r_w;
-                const int n = m / hw, rem = m - n * hw;
-                const int yy = rem / r_w;
-                a_n[j] = n; a_y[j] = r_y0 + yy; a_x[j] = r_x0 + rem - yy * r_w;
-            } else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
-            a_off[j] = -1;
-        } else {
-            a_n[j] = 0; a_y[j] = 0; a_x[j] = 0;
-            a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
-        }
-    }
-    if (GATHER && p_taps > 1 && !p_rect) {
-        if (tid == 0) *s_mask = 0u;
-        __syncthreads();
-        if (ac == 0) {
-            unsigned local = 0;
-            for (unsigned mm = mask; mm; mm &= mm - 1) {
-                const int t = __ffs(mm) - 1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (a_n[j] >= 0 && map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
-            }
-            if (local) atomicOr(s_mask, local);
-        }
-        __syncthreads();
-        mask &= *s_mask;
-    }
-
-    const int nkc = pK / BK;
-    const int ntiles = __popc(mask) * nkc;
-    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-    float4 ra[4], rb[4];
-    unsigned rem_mask = mask;
-    int tap = -1, kc = nkc;
-    const float* pa[4];
-    const float* pb[4];
-    unsigned a_ok = 0;
-
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (++kc >= nkc) {
-            kc = 0;
-            tap = __ffs(rem_mask) - 1;
-            rem_mask &= rem_mask - 1;
-            a_ok = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                long long off;
-                if (GATHER) {
-                    const int sr = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
-                    off = (sr >= 0) ? (long long)sr * p_lda : -1;
-                } else {
-                    off = a_off[j];
-                }
-                a_ok |= (off >= 0 ? 1u : 0u) << j;
-                pa[j] = A + (off >= 0 ? off : 0) + 4 * ac;
-            }
-            const float* Bt = B + (long long)tap * p_tsb;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pb[j] = Bt + (long long)min(tn * BN + ar + 32 * j, pN - 1) * p_ldb + 4 * ac;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { pa[j] += BK; pb[j] += BK; }
-        }
-    };
-#define GLF_S_LOAD()                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const float4*>(pb[j]);
-#define GLF_S_STORE_A(J)                                                                                   \
-    {                                                                                                      \
-        const Split4 s = split4(keep_if((a_ok >> J) & 1u, ra[J]));                                         \
-        unsigned char* d = As + (ar + 32 * J) * RS + ac * 8;                                               \
-        *reinterpret_cast<bf16x4*>(d) = s.h; *reinterpret_cast<bf16x4*>(d + PLANE) = s.m; *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = s.l; \
-    }
-#define GLF_S_STORE_B(J)                                                                                   \
-    {                                                                                                      \
-        const Split4 s = split4(keep_if(tn * BN + ar + 32 * J < pN, rb[J]));                               \
-        unsigned char* d = Bs + (ar + 32 * J) * RS + ac * 8;                                               \
-        *reinterpret_cast<bf16x4*>(d) = s.h; *reinterpret_cast<bf16x4*>(d + PLANE) = s.m; *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = s.l; \
-    }
-
-    if (ntiles > 0) {
-        const int frag = (lane & 31) * RS + (lane >> 5) * 16;      // byte offset of this lane's fragment in a tile row block
-        const unsigned char* a_fr = As + wm * RS + frag;
-        const unsigned char* b_fr = Bs + wn * RS + frag;
-        advance();
-        GLF_S_LOAD()
-        for (int it = 0; it < ntiles; ++it) {
-#if GLF_EXPS != 2
-            GLF_S_STORE_A(0) GLF_S_STORE_A(1) GLF_S_STORE_A(2) GLF_S_STORE_A(3)
-            GLF_S_STORE_B(0) GLF_S_STORE_B(1) GLF_S_STORE_B(2) GLF_S_STORE_B(3)
-#endif
-            __syncthreads();
-#if GLF_EXPS == 3
-            if (it + 1 < ntiles) { advance(); }
-#else
-            if (it + 1 < ntiles) { advance(); GLF_S_LOAD() }      // in flight during the MFMA phase
-#endif
-#if GLF_EXPS == 4
-            float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f, pf4 = 0.f, pf5 = 0.f, pf6 = 0.f, pf7 = 0.f;
-            const bool do_pf = (kc + 2 < nkc);
-            if (do_pf) { pf0 = pa[0][BK]; pf1 = pa[1][BK]; pf2 = pa[2][BK]; pf3 = pa[3][BK]; pf4 = pb[0][BK]; pf5 = pb[1][BK]; pf6 = pb[2][BK]; pf7 = pb[3][BK]; }
-#endif
-            f32x16 t00 = {0}, t01 = {0}, t10 = {0}, t11 = {0};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(b_fr + s * 32);
-                const bf16x8 b0m = *reinterpret_cast<const bf16x8*>(b_fr + s * 32 + PLANE);
-                const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(b_fr + s * 32 + 2 * PLANE);
-                const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(b_fr + 32 * RS + s * 32);
-                const bf16x8 b1m = *reinterpret_cast<const bf16x8*>(b_fr + 32 * RS + s * 32 + PLANE);
-                const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(b_fr + 32 * RS + s * 32 + 2 * PLANE);
-                {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_fr + s * 32);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(a_fr + s * 32 + PLANE);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_fr + s * 32 + 2 * PLANE);
-                    GLF_SIX(t00, ah, am, al, b0h, b0m, b0l)
-                    GLF_SIX(t01, ah, am, al, b1h, b1m, b1l)
-                }
-                {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_fr + 32 * RS + s * 32);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(a_fr + 32 * RS + s * 32 + PLANE);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_fr + 32 * RS + s * 32 + 2 * PLANE);
-                    GLF_SIX(t10, ah, am, al, b0h, b0m, b0l)
-                    GLF_SIX(t11, ah, am, al, b1h, b1m, b1l)
-                }
-            }
-            c00 += t00; c01 += t01; c10 += t10; c11 += t11;          // two-level accumulation (see gemm_f32.hip)
-#if GLF_EXPS == 4
-            asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3), "v"(pf4), "v"(pf5), "v"(pf6), "v"(pf7));
-#endif
-            __syncthreads();
-        }
-    }
-
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    auto emit = [&](const f32x16& acc, int ti, int tj) {
-        const int col = tn * BN + wn + 32 * tj + col_l;
-        if (col >= pN) return;
-        const float bv = p_bias ? p_bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row < pMe) {
-                if (p_rect) {
-                    const int hw = r_h * r_w;
-                    const int n = row / hw, rem = row - n * hw;
-                    const int yy = rem / r_w;
-                    const long long orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
-                    atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
-                } else {
-                    float* dst = C + (long long)row * p_ldc + col;
-                    float v = p_alpha * acc[r] + bv;
-                    if (p_accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
-    };
-    emit(c00, 0, 0); emit(c01, 0, 1); emit(c10, 1, 0); emit(c11, 1, 1);
-}
-
-// ----------------------------------------------------------------------------------------------------------
-// rows kernel v2 (the one that is launched): 512 threads = 8 waves (4 x 2), tile 256 x 128 x 32, two LDS buffers.
+// rows kernel, NT: C[m][n] = alpha * sum_tap sum_k A[src(m,tap)][k] * B_tap[n][k] (+ bias).  512 threads = 8 waves (4 x 2), tile 256 x 128 x 32, two LDS buffers.
 //   * LDS planes have unpadded 64-byte rows ([row][32 bf16]) with the 16-byte chunk index XOR-swizzled by
 //     (row >> 2) & 3, so both the staging writes (ds_write_b64) and the fragment reads (ds_read_b128) are
 //     conflict-free: 2 buffers x (3 x 256 + 3 x 128 rows) x 64 B = 144 KB of the CU's 160 KB.
@@ -720,8 +499,6 @@ int init_gemm_bf16s_attrs() {
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
     SET_ATTR((gemm_rows_bf16s8_kernel<false>), SMEM_ROWS_S8)
     SET_ATTR((gemm_rows_bf16s8_kernel<true>), SMEM_ROWS_S8)
-    SET_ATTR((gemm_rows_bf16s_kernel<false>), SMEM_ROWS_S)
-    SET_ATTR((gemm_rows_bf16s_kernel<true>), SMEM_ROWS_S)
     SET_ATTR((gemm_tn_bf16s_kernel<false>), SMEM_TN_S)
     SET_ATTR((gemm_tn_bf16s_kernel<true>), SMEM_TN_S)
 #undef SET_ATTR
@@ -736,7 +513,7 @@ bool bf16s_tn_ok(const GemmArgs& a) {
     return a.vec_a && a.vec_b && (a.M % 4) == 0 && (a.N % 4) == 0 && a.M >= 4 && a.N >= 4;
 }
 
-// v2 (256-row tiles, 8 waves): the grid is re-derived for BM8; rect mode sums its tiles per tap as setup_rect does
+// 256-row tiles: the grid is re-derived for BM8; rect mode sums its tiles per tap as setup_rect does
 int launch_rows_bf16s8(const GemmArgs& a0, bool gather, int batch, hipStream_t s) {
     GemmArgs a = a0;
     long long tiles_m = (a.M + BM8 - 1) / BM8;
@@ -757,10 +534,7 @@ int launch_rows_bf16s8(const GemmArgs& a0, bool gather, int batch, hipStream_t s
 }
 
 int launch_rows_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s) {
-    if (getenv("GLF_BF16S_V1") == nullptr) return launch_rows_bf16s8(a, gather, (int)grid.z, s);
-    if (gather) hipLaunchKernelGGL((gemm_rows_bf16s_kernel<true>), grid, dim3(NTHREADS), SMEM_ROWS_S, s, a);
-    else hipLaunchKernelGGL((gemm_rows_bf16s_kernel<false>), grid, dim3(NTHREADS), SMEM_ROWS_S, s, a);
-    return check_launch("gemm_nt(bf16x6)");
+    return launch_rows_bf16s8(a, gather, (int)grid.z, s);
 }
 int launch_tn_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s) {
     if (gather) hipLaunchKernelGGL((gemm_tn_bf16s_kernel<true>), grid, dim3(NTHREADS), SMEM_TN_S, s, a);

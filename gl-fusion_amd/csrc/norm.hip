@@ -128,10 +128,19 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ partial
                                               double& s, double& q, double* sh) {
     s = 0; q = 0;
     if (ch < c) {
-        for (int i = lane; i < slices; i += FIN_LANES) {
+        double s1 = 0, q1 = 0, s2 = 0, q2 = 0, s3 = 0, q3 = 0;      // four independent chains: the loop is latency-bound
+        int i = lane;
+        for (; i + 3 * FIN_LANES < slices; i += 4 * FIN_LANES) {
+            s += partial[(long long)i * c + ch];                     q += partial[(long long)(slices + i) * c + ch];
+            s1 += partial[(long long)(i + FIN_LANES) * c + ch];      q1 += partial[(long long)(slices + i + FIN_LANES) * c + ch];
+            s2 += partial[(long long)(i + 2 * FIN_LANES) * c + ch];  q2 += partial[(long long)(slices + i + 2 * FIN_LANES) * c + ch];
+            s3 += partial[(long long)(i + 3 * FIN_LANES) * c + ch];  q3 += partial[(long long)(slices + i + 3 * FIN_LANES) * c + ch];
+        }
+        for (; i < slices; i += FIN_LANES) {
             s += partial[(long long)i * c + ch];
             q += partial[(long long)(slices + i) * c + ch];
         }
+        s += (s1 + s2) + s3; q += (q1 + q2) + q3;
     }
     const int t = threadIdx.x;
     sh[t] = s; sh[256 + t] = q;

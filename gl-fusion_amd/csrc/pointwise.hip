@@ -348,6 +348,16 @@ __global__ __launch_bounds__(256) void add_frames_kernel(const float4* __restric
     }
 }
 
+// n-ary sum (gradient fan-in of a tensor consumed by several branches): one pass, k reads + 1 write
+struct AddNPtrs { const float4* p[8]; };
+__global__ __launch_bounds__(256) void add_n_kernel(AddNPtrs in, int k, float4* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 a = in.p[0][i];
+        for (int j = 1; j < k; ++j) { const float4 b = in.p[j][i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        out[i] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // row softmax (embedded mode), one workgroup per row
 // ---------------------------------------------------------------------------------------
@@ -658,6 +668,20 @@ extern "C" int glf_add_frames(const float* a, int64_t a_fs, const float* b, int6
                        (long long)(a_fs / 4), reinterpret_cast<const float4*>(b), (long long)(b_fs / 4), reinterpret_cast<float4*>(dst),
                        (long long)(dst_fs / 4), (long long)(inner / 4), total4);
     return glf::check_launch("add_frames");
+}
+
+extern "C" int glf_add_n(const float* const* inputs, int k, float* out, int64_t numel, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(inputs && out, GLF_ERR_NULL, "add_n: null argument");
+    GLF_REQUIRE(k >= 1 && k <= 8 && numel > 0 && (numel % 4) == 0, GLF_ERR_BAD_SHAPE, "add_n: 1 <= k <= 8 and numel %% 4 == 0 required");
+    AddNPtrs ptrs;
+    for (int j = 0; j < 8; ++j) {
+        ptrs.p[j] = reinterpret_cast<const float4*>(inputs[j < k ? j : 0]);
+        GLF_REQUIRE(ptrs.p[j] != nullptr && al16(ptrs.p[j]), GLF_ERR_BAD_SHAPE, "add_n: inputs must be non-null and 16-byte aligned");
+    }
+    GLF_REQUIRE(al16(out), GLF_ERR_BAD_SHAPE, "add_n: out must be 16-byte aligned");
+    hipLaunchKernelGGL(add_n_kernel, dim3(stream_grid(numel / 4, 256)), dim3(256), 0, glf::S(s), ptrs, k, reinterpret_cast<float4*>(out), (long long)(numel / 4));
+    return glf::check_launch("add_n");
 }
 
 extern "C" int glf_softmax_rows(float* x, int64_t rows, int cols, glf_stream_t s) {

@@ -72,7 +72,8 @@ class ASPP(nn.Module):
                                      BatchNorm2d(out_channels), ReLU(), Dropout(0.5))
 
     def forward_nhwc(self, x):
-        branches = [conv.forward_nhwc(x) for conv in self.convs]
+        xs = ops.fan_out(x, len(self.convs))              # one-pass gradient fan-in over the five branches
+        branches = [conv.forward_nhwc(xi) for conv, xi in zip(self.convs, xs)]
         y = ops.conv1x1_cat(self.project[0].weight, branches)
         y = self.project[1].forward_nhwc(y, relu=True)
         return self.project[3].forward_nhwc(y)

@@ -113,12 +113,14 @@ class Global_and_Local(nn.Module):
         f4 = self._encode(x)
         # M_cls, M_ctr, local features (ours.py:1802-1816)
         f4_local = {}
+        f4_glob = {}
         for v in views:
-            cls = self.classifier[v].forward_nhwc(f4[v])
-            ctr = self.centerness[v].forward_nhwc(f4[v])
-            f4_local[v] = ops.local_gate(cls, ctr, f4[v], self.center_aware_weight)
+            fa, fb, fc, f4_glob[v] = ops.fan_out(f4[v], 4)  # classifier / centerness / gate / global fusion
+            cls = self.classifier[v].forward_nhwc(fa)
+            ctr = self.centerness[v].forward_nhwc(fb)
+            f4_local[v] = ops.local_gate(cls, ctr, fc, self.center_aware_weight)
         # global / local cross-view fusion (ours.py:1819-1830)
-        g_out = self.global_attn.forward_nvhwc(ops.stack_views([f4[v] for v in views]))        # [N,V,h,w,C]
+        g_out = self.global_attn.forward_nvhwc(ops.stack_views([f4_glob[v] for v in views]))   # [N,V,h,w,C]
         l_out = self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))
         fused = ops.add_views(g_out, l_out)                                                     # ours.py:1833-1834
         mask, mask_bb, f4_g, f4_l = {}, {}, {}, {}

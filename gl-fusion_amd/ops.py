@@ -637,6 +637,39 @@ def broadcast_hw(x, h: int, w: int):
     return BroadcastFn.apply(x, h, w)
 
 
+class FanOutFn(Function):
+    """Identity with k outputs; backward sums the k incoming gradients in ONE pass (k reads + 1 write) instead of
+    autograd's pairwise accumulation (3 (k-1) tensor passes through torch's add kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, k: int):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        live = [_contig(d) for d in dys if d is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        out = torch.empty_like(live[0])
+        n = out.numel()
+        if n % 4 != 0 or any(d.shape != out.shape for d in live) or len(live) > 8:
+            raise RuntimeError("fan_out: gradients must share one shape with numel % 4 == 0 (<= 8 branches)")
+        arr = (C.c_void_p * len(live))(*[d.data_ptr() for d in live])
+        check(lib.glf_add_n(arr, len(live), _p(out), n, _stream()), "add_n")
+        return out, None
+
+
+def fan_out(x: torch.Tensor, k: int):
+    """k aliases of x for k consumers (use each exactly once)."""
+    if k <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return tuple(x for _ in range(max(k, 1)))
+    return FanOutFn.apply(x, k)
+
+
 # ----------------------------------------------------------------------------------------
 # local gate (ours.py:1802-1816)
 # ----------------------------------------------------------------------------------------

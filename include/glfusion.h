@@ -193,6 +193,9 @@ int glf_copy_frames(const float* src, int64_t src_fs, float* dst, int64_t dst_fs
 /* dst = a + b with independent frame strides (f4_fusion = f4_global_fusion + f4_local_fusion). */
 int glf_add_frames(const float* a, int64_t a_fs, const float* b, int64_t b_fs, float* dst, int64_t dst_fs,
                    int n, int64_t inner, glf_stream_t s);
+/* out = sum of k (<= 8) same-sized tensors given as a HOST array of device pointers: the gradient fan-in of a
+ * tensor that feeds several branches (f4 -> classifier / centerness / gate / fusion; ASPP input -> 5 branches). */
+int glf_add_n(const float* const* inputs, int k, float* out, int64_t numel, glf_stream_t s);
 /* W_z tail of TPAVIModule (ours.py:908-915): z = LayerNorm_C( BN(w) + x ) with the BN already
  * folded into per-channel (bn_mean, bn_invstd, gamma, beta).  Saves row mean / rstd. */
 int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn_mean, const float* bn_invstd,
