@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
     ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("GLF_PRECISION", "bf16x6"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -189,6 +190,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # secondary figure, outside the timed region: the same step on the exact-fp32 MFMA kernels (2 steps)
+    exact = None
+    if args.precision != "f32" and not args.no_exact_f32:
+        ops.set_precision("f32")
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        te = torch.tensor([(time.perf_counter() - t1) / 2], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        exact = {"value": round(args.clips * world / float(te.item()), 4), "unit": "clips/s", "ms_per_step": round(float(te.item()) * 1e3, 2),
+                 "arithmetic": "v_mfma_f32_32x32x2_f32 (exact fp32), same step, 2 timed steps after 1 warm-up"}
+        ops.set_precision(args.precision)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         clips_total = args.clips * world * args.steps
@@ -247,6 +265,8 @@ def main():
             "loss": loss_val, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
             "roofline": roofline,
         }
+        if exact is not None:
+            out["exact_f32"] = exact
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

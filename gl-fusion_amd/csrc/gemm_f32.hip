@@ -19,9 +19,6 @@
 //   gemm_rows_kernel<1>  A[m][k] (gathered rows) x B[k][n]   -> conv dgrad, y = theta @ M
 //   gemm_tn_kernel       sum_r A[r][m] * B[src(r)][n]        -> conv wgrad, M = phi^T g
 #include "gemm_common.h"
-#ifndef GLF_EXP
-#define GLF_EXP 0
-#endif
 
 namespace {
 
@@ -38,11 +35,7 @@ namespace {
 // Written as a macro (not a function taking a closure): nested lambdas that capture the staging registers by
 // reference made hipcc materialise the closures -- and everything they point to -- in scratch memory.
 // MID(pc) is a statement macro of the enclosing kernel; pc is a compile-time constant after unrolling.
-#if GLF_EXP == 4
-#define GLF_LD(x) (1.0f + (float)(lane))      /* timing experiment: no LDS operand reads */
-#else
 #define GLF_LD(x) (x)
-#endif
 // MID(q), q = 0..11, is called after the MFMAs of head k-step q (HEAD_ = 12).
 #define GLF_MMA_KTILE(LDA_, LDB_, a_s, b_s, MID)                                                              \
     {                                                                                                         \
@@ -327,7 +320,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
         if ((q) < 4) { GLF_FLP(2 * (q)) GLF_FLP(2 * (q) + 1) }                \
         else { GLF_FSP((q) - 4) }                                             \
     }
-#define GLF_NO_MID(q)
 
     if (ntiles > 0) {
         const int a_lane = (lane >> 5) * LDA + wm + (lane & 31);
@@ -348,11 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs a
                 const float* a_sp = As + (it & 1) * A_SZ + a_lane;
                 const float* b_sp = Bs + (it & 1) * B_SZ + b_lane;
                 const int buf = (it & 1) ^ 1;      // the staging macros write the OTHER buffer (free since the last barrier)
-#if GLF_EXP == 2
-                GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_NO_MID)
-#else
                 GLF_MMA_KTILE(LDA, LDB, a_sp, b_sp, GLF_FAST_MID)
-#endif
                 __syncthreads();
             }
         } else {
