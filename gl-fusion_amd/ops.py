@@ -492,6 +492,9 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
     """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
     optionally fused with a residual add and ReLU."""
     training = bn.training or bn.running_mean is None
+    if training and x.numel() // x.shape[-1] <= 1:
+        # same refusal (and wording) as torch.nn.functional.batch_norm in train mode
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(from_nhwc(x).shape) if x.dim() == 4 else list(x.shape)}")
     momentum = 0.0 if bn.momentum is None else float(bn.momentum)
     if bn.momentum is None and training and bn.track_running_stats:
         raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")

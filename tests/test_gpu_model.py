@@ -239,3 +239,37 @@ def test_e2e_train_step_vs_golden(golden_dir, precision):
             flat = sd[k[3:]].reshape(-1).float()
             idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(9, flat.numel())).astype(np.int64))
             assert close(flat[torch.from_numpy(idx).to(DEV)], g[k], 1e-5), k
+
+
+@pytest.mark.parametrize("views,n,h,w", [(["1"], 3, 96, 80), (["2", "4"], 1, 112, 112)])
+def test_ragged_shapes_eval_vs_oracle(views, n, h, w, precision):
+    """Non-square / non-112 inputs, a single frame, two views: eval forward vs the oracle (no golden exists for these;
+    the oracle itself is pinned on the standard shapes)."""
+    from glfusion_amd.models import Global_and_Local
+    ref = orc.Global_and_Local(views)
+    orc.closed_form_fill(ref, salt=2)
+    ref.eval()
+    model = Global_and_Local(views)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(DEV).eval()
+    imgs = orc.closed_form_images(views, n, h, w)
+    with torch.no_grad():
+        want = ref(imgs)
+        got = model({v: t.to(DEV) for v, t in imgs.items()})
+    for v in views:
+        assert tuple(got[0][v].shape) == (n, 5, h, w)
+        assert close(got[0][v], want[0][v]), v
+        assert close(got[1][v], want[1][v]), v
+        assert close(got[2][v], want[2][v], 1e-3), v
+        assert close(got[3][v], want[3][v], 1e-3), v
+
+
+def test_error_behaviour_matches_torch():
+    from glfusion_amd.models import DeepLabHead
+    head = DeepLabHead(64, 5).to(DEV).train()
+    x = torch.rand(1, 64, 28, 28, device=DEV)
+    # N = 1 in train(): the pooled ASPP branch has one value per channel -- PyTorch refuses, so do we
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        head(x)
+    head.eval()
+    assert tuple(head(x).shape) == (1, 5, 28, 28)
