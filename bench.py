@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
-    ap.add_argument("--precision", choices=["f32", "bf16x6"], default=os.environ.get("GLF_PRECISION", "bf16x6"),
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
                          "passes the same parity gates; default) or f32 = exact v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
@@ -234,20 +234,24 @@ def main():
         name, (secs, dense, kept, launches) = dom
         all_secs = sum(a[0] for a in agg.values())
         all_dense = sum(a[1] for a in agg.values())
-        split = args.precision == "bf16x6"
+        split = args.precision != "f32"
+        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3}[args.precision]
         # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
         # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
         #         bf16 FLOPs / time against the dense bf16 MFMA peak; the fp32-equivalent rates are given beside it
+        #         (f16x3: THREE fp16 MFMA FLOPs per algorithmic FLOP, same dense 16-bit peak)
         if split:
-            achieved, peak = 6.0 * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
-            kname = name.replace("gemm_rows_kernel<0,", "gemm_rows_bf16s8_kernel<").replace("gemm_tn_kernel<", "gemm_tn_bf16s_kernel<")
+            achieved, peak = nmul * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
+            fam = "bf16s" if args.precision == "bf16x6" else "f16s"
+            kname = name.replace("gemm_rows_kernel<0,", f"gemm_rows_{fam}8_kernel<").replace("gemm_tn_kernel<", f"gemm_tn_{fam}_kernel<")
         else:
             achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
         roofline = {
             "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic_per_launch(kname, args.precision),
-            "arithmetic": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate" if split
-                          else "v_mfma_f32_32x32x2_f32 (exact fp32)",
+            "arithmetic": {"f32": "v_mfma_f32_32x32x2_f32 (exact fp32)",
+                           "bf16x6": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate",
+                           "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate"}[args.precision],
             "launches_per_step": launches // args.steps, "avg_launch_ms": round(secs / launches * 1e3, 4),
             "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
             "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2), "share_of_step": round(all_secs / dt, 4),
@@ -258,7 +262,8 @@ def main():
             "metric": "clips/sec fwd+bwd (B=4, 3 views x16x112x112) per GPU, weak scaling", "value": round(value, 4),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)" if split else "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
+                      "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
                        "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},

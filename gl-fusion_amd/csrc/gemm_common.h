@@ -18,15 +18,26 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int vec_a, vec_b;
     int rect;       // tap-parallel rectangle mode (see tap_rect)
+    const float* amax_a; const float* amax_b;   // f16x3 only: device scalars bounding max|A|, max|B| (null = no scaling)
+    const float* zeros;                         // f16x3 only: device page of ZERO_PAGE_FLOATS zeros
 };
+constexpr int ZERO_PAGE_FLOATS = 1 << 18;
 
 
-int precision();                               // 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x6); glf_api.hip
+int precision();                               // 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x6), 2 = split-fp16 (f16x3); glf_api.hip
 int init_gemm_bf16s_attrs();                   // gemm_bf16s.hip
 bool bf16s_rows_ok(const GemmArgs& a);
 bool bf16s_tn_ok(const GemmArgs& a);
 int launch_rows_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int launch_tn_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+int init_gemm_f16s_attrs();                    // gemm_f16s.hip
+int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s);
+float* amax_scratch(int n);                    // n consecutive device floats from a ring (glf_api.hip)
+const float* zero_page();                      // ZERO_PAGE_FLOATS zeros on the device (glf_api.hip)
+bool f16s_rows_ok(const GemmArgs& a);
+bool f16s_tn_ok(const GemmArgs& a);
 }  // namespace glf
 
 namespace {
@@ -131,6 +142,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr;
     return a;
 }
 

@@ -1,0 +1,587 @@
+// Split-fp16 ("f16x3") contraction kernels: fp32-class GEMM on the fp16 matrix cores of gfx950 with THREE MFMAs per
+// product instead of the six of gemm_bf16s.hip.
+//
+// Each operand is first multiplied by a power of two s = 2^(13 - floor(log2 amax)) derived from the operand's max
+// magnitude (a device scalar: glf_gemm_params.amax_a / amax_b, produced by glf_amax or by the kernel that wrote the
+// operand), so that |x s| < 2^14 sits at the top of the fp16 range.  x s is then split into two fp16 pieces
+//      x s = h + 2^-11 l + e,      h = rne16(x s),   l = rne16((x s - h) 2^11),   |e| <= 2^-22 |x s|
+// (full 22-bit precision for every element within 2^-27 of amax, an absolute error floor of 2^-49 amax below), and
+//      a*b ~= ha*hb + 2^-11 (ha*lb + la*hb)                                    (dropped la*lb <= 2^-22 |a*b|)
+// is evaluated with three v_mfma_f32_32x32x16_f16 per 16 k: the main product accumulates in one fp32 accumulator,
+// the two mixed products in a second one that is folded in (times 2^-11) by the epilogue, where the operand
+// powers of two are undone exactly as well.  That is 96 MFMA cycles per 16 k against 192 (bf16x6) and 512 (exact
+// fp32 MFMA).  The MFMA sums 16 k per instruction, so the accumulation chain is K/16 long -- no per-tile
+// two-level fold is needed to stay at the fp32 kernels' error level (tests/test_gpu_ops.py measure it vs fp64).
+// Rows that must read as zero (conv padding, tile overhang) are LOADED from a zero page (args.zeros) instead of
+// being masked after the load: no per-element selects in the staging path.
+//
+// Same tiling, LDS swizzle, software pipeline, gather / tap_mask / rect semantics and XCD-aware tile order as
+// gemm_bf16s.hip, with two planes per operand instead of three (96 KB of LDS).  Only the aligned fast path is
+// built; everything else stays on the exact-fp32 kernels.
+#include "gemm_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct SplitH { f16x4 h, l; };
+
+// x*s = h + 2^-11 l: 2 pk_mul + 2 cvt_pk + 4 cvt_f32 + 2 pk_add + 2 pk_mul + 2 cvt_pk per four elements
+__device__ __forceinline__ SplitH split4h(const float4 v, const float s) {
+    const f32x2 s2 = {s, s}, k2 = {2048.f, 2048.f};
+    const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+    const f32x2 x01 = v01 * s2, x23 = v23 * s2;
+    const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
+    const f32x2 r01 = (x01 - __builtin_convertvector(h01, f32x2)) * k2;
+    const f32x2 r23 = (x23 - __builtin_convertvector(h23, f32x2)) * k2;
+    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+    SplitH o;
+    o.h = __builtin_shufflevector(h01, h23, 0, 1, 2, 3);
+    o.l = __builtin_shufflevector(l01, l23, 0, 1, 2, 3);
+    return o;
+}
+
+// power-of-two operand scale from its max magnitude: amax*s in [2^13, 2^14); inv = 1/s.  No pointer, zero,
+// denormal-range or non-finite amax: s = 1.
+__device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& inv) {
+    s = 1.f; inv = 1.f;
+    if (amax) {
+        const int e = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+        if (e >= 20 && e <= 250) {
+            s = __uint_as_float((unsigned)(267 - e) << 23);
+            inv = __uint_as_float((unsigned)(e - 13) << 23);
+        }
+    }
+}
+
+#define GLF_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// one A tile-row against both B tile-cols for one 16-deep k-step: main products into c, mixed products into m
+// (dependent MFMAs are two apart)
+#define GLF_ROW3(c0, c1, m0, m1, ah, al, b0h, b0l, b1h, b1l)  \
+    c0 = GLF_MFMA_F16(ah, b0h, c0);                         \
+    c1 = GLF_MFMA_F16(ah, b1h, c1);                         \
+    m0 = GLF_MFMA_F16(al, b0h, m0);                         \
+    m1 = GLF_MFMA_F16(al, b1h, m1);                         \
+    m0 = GLF_MFMA_F16(ah, b0l, m0);                         \
+    m1 = GLF_MFMA_F16(ah, b1l, m1);
+
+// ----------------------------------------------------------------------------------------------------------
+// rows kernel, NT.  512 threads = 8 waves (4 x 2), tile 256 x 128 x 32, THREE LDS buffers of 2 x (256 + 128) rows
+// (144 KB).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int BM8 = 256;
+constexpr int NT8 = 512;
+constexpr int PL_A8 = BM8 * 64, PL_B8 = BN * 64;
+constexpr int BUF8 = 2 * PL_A8 + 2 * PL_B8;
+constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
+
+template <bool GATHER>
+__global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
+    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
+    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
+    const int p_tiles_n = args.tiles_n;
+    const unsigned p_tap_mask = args.tap_mask;
+    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B; const float* __restrict__ p_bias = args.bias;
+    float* __restrict__ p_C = args.C;
+    const float* __restrict__ p_zero = args.zeros;
+    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
+    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
+    float sc_a, sc_b, inv_a, inv_b;
+    pow2_scale(args.amax_a, sc_a, inv_a);
+    pow2_scale(args.amax_b, sc_b, inv_b);
+    const float p_alpha = args.alpha * inv_a * inv_b;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    unsigned* s_mask = reinterpret_cast<unsigned*>(smem_s + 3 * BUF8);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p_tiles_n;
+    int tm = bid / p_tiles_n;
+    int pMe = pM;
+    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd;
+    unsigned mask = p_tap_mask;
+    if (p_rect) {
+        for (unsigned mm = p_tap_mask; mm; mm &= mm - 1) {
+            const int t = __ffs(mm) - 1;
+            int y0, y1, x0, x1;
+            tap_rect(p_gather, t, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
+            const int mt = g_nimg * (y1 - y0) * (x1 - x0);
+            const int tiles = (mt + BM8 - 1) / BM8;
+            if (tm < tiles || (mm & (mm - 1)) == 0) { mask = 1u << t; pMe = mt; r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0; break; }
+            tm -= tiles;
+        }
+    }
+    const int bz = blockIdx.z;
+    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    float* __restrict__ C = p_C + (long long)bz * p_bsc;
+
+    const int ac = tid & 7, ar = tid >> 3;              // 8 float4 per 32-deep row; rows ar + 64 j
+
+    int a_n[4], a_y[4], a_x[4];
+    long long a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = tm * BM8 + ar + 64 * j;
+        if (GATHER) {
+            if (m < pMe) {
+                const int hw = r_h * r_w;
+                const int n = m / hw, rem = m - n * hw;
+                const int yy = rem / r_w;
+                a_n[j] = n; a_y[j] = r_y0 + yy; a_x[j] = r_x0 + rem - yy * r_w;
+            } else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
+            a_off[j] = -1;
+        } else {
+            a_n[j] = 0; a_y[j] = 0; a_x[j] = 0;
+            a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
+        }
+    }
+    if (GATHER && p_taps > 1 && !p_rect) {
+        if (tid == 0) *s_mask = 0u;
+        __syncthreads();
+        if (ac == 0) {
+            unsigned local = 0;
+            for (unsigned mm = mask; mm; mm &= mm - 1) {
+                const int t = __ffs(mm) - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (a_n[j] >= 0 && map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
+            }
+            if (local) atomicOr(s_mask, local);
+        }
+        __syncthreads();
+        mask &= *s_mask;
+    }
+
+    const int nkc = pK / BK;
+    const int ntiles = __popc(mask) * nkc;
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};      // main products
+    f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};      // mixed products (x 2^11)
+    float4 ra[4], rb[2];
+    unsigned rem_mask = mask;
+    int tap = -1, kc = nkc;
+    const float* pa[4];
+    const float* pb[2];
+
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++kc >= nkc) {
+            kc = 0;
+            tap = __ffs(rem_mask) - 1;
+            rem_mask &= rem_mask - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                long long off;
+                if (GATHER) {
+                    const int sr = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
+                    off = (sr >= 0) ? (long long)sr * p_lda : -1;
+                } else {
+                    off = a_off[j];
+                }
+                pa[j] = (off >= 0 ? A + off : p_zero) + 4 * ac;          // padding / overhang rows read the zero page
+            }
+            const float* Bt = B + (long long)tap * p_tsb;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = tn * BN + ar + 64 * j;
+                pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + 4 * ac;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pa[j] += BK;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pb[j] += BK;
+        }
+    };
+    // swizzled staging offset of this thread inside a 64-byte row: 16-byte chunk (ac>>1) ^ ((row>>2)&3), half ac&1
+    const int st_off = ar * 64 + ((((ac >> 1) ^ ((ar >> 2) & 3)) << 4) | ((ac & 1) << 3));
+#define GLF_H8_CONV_A(J, buf_)                                                                               \
+    {                                                                                                        \
+        const SplitH s = split4h(ra[J], sc_a);                                                               \
+        unsigned char* d = smem_s + (buf_) * BUF8 + st_off + J * 64 * 64;                                    \
+        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;                      \
+    }
+#define GLF_H8_CONV_B(J, buf_)                                                                               \
+    {                                                                                                        \
+        const SplitH s = split4h(rb[J], sc_b);                                                               \
+        unsigned char* d = smem_s + (buf_) * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64;                        \
+        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;                      \
+    }
+    // piece pc (0..5): convert + store registers of tile t+1, then refill them with tile t+2
+#define GLF_H8_PIECE(pc, buf_, conv_, load_)                                                                 \
+    switch (pc) {                                                                                            \
+        case 0: if (conv_) GLF_H8_CONV_A(0, buf_) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0]); break; \
+        case 1: if (conv_) GLF_H8_CONV_A(1, buf_) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); break; \
+        case 2: if (conv_) GLF_H8_CONV_A(2, buf_) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); break; \
+        case 3: if (conv_) GLF_H8_CONV_A(3, buf_) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); break; \
+        case 4: if (conv_) GLF_H8_CONV_B(0, buf_) if (load_) rb[0] = *reinterpret_cast<const float4*>(pb[0]); break; \
+        default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); break; \
+    }
+
+    if (ntiles > 0) {
+        const int sw = (lane >> 2) & 3, hh = lane >> 5;
+        const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
+        const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
+        // Pipeline state at the top of iteration `it`: tiles it and it+1 sit converted in LDS buffers it%3 and
+        // (it+1)%3, tile it+2 raw in registers, the k-step-0 fragments of tile it in f*.  The iteration multiplies
+        // tile it, converts tile it+2 into buffer (it+2)%3, loads tile it+3 and -- after its first k-step --
+        // prefetches the k-step-0 fragments of tile it+1, so no LDS latency is exposed behind the barrier.
+        advance();
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, false, true) }
+        {
+            const bool more = ntiles > 1;
+            if (more) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, true, more) }
+            if (more) {
+                const bool more2 = ntiles > 2;
+                if (more2) advance();
+#pragma unroll
+                for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 1, true, more2) }
+            }
+        }
+        __syncthreads();
+        f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l;
+#define GLF_H8_FRAGS(P, buf_, fo_)                                                                            \
+        {                                                                                                     \
+            const unsigned char* ab_ = smem_s + (buf_) * BUF8 + wm * 64 + (fo_);                              \
+            const unsigned char* bb_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + wn * 64 + (fo_);                  \
+            P##b0h = *reinterpret_cast<const f16x8*>(bb_);                                                    \
+            P##b1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                          \
+            P##a0h = *reinterpret_cast<const f16x8*>(ab_);                                                    \
+            P##a0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                            \
+            P##b0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                            \
+            P##b1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                                  \
+            P##a1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                          \
+            P##a1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                                  \
+        }
+        GLF_H8_FRAGS(f, 0, fo0)
+        int cur = 0, nxt = 1, wr = 2;           // LDS buffers of tile it, it+1, it+2
+        // CONV_/LOAD_/NEXT_ are compile-time constants: the steady-state body is straight-line code
+#define GLF_H8_BODY(CONV_, LOAD_, NEXT_)                                                                      \
+        {                                                                                                     \
+            if (LOAD_) advance();                                                                             \
+            f16x8 gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;                                             \
+            GLF_H8_FRAGS(g, cur, fo1)                                                                         \
+            __builtin_amdgcn_sched_barrier(0);    /* keep the fragment reads up here (hipcc sinks them to their use) */ \
+            GLF_H8_PIECE(0, wr, CONV_, LOAD_)                                                                 \
+            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_H8_PIECE(1, wr, CONV_, LOAD_)                                                                 \
+            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_H8_PIECE(2, wr, CONV_, LOAD_)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if (NEXT_) GLF_H8_FRAGS(f, nxt, fo0)                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_H8_PIECE(3, wr, CONV_, LOAD_)                                                                 \
+            GLF_ROW3(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l)                                  \
+            GLF_H8_PIECE(4, wr, CONV_, LOAD_)                                                                 \
+            GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
+            GLF_H8_PIECE(5, wr, CONV_, LOAD_)                                                                 \
+            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            __syncthreads();                                                                                  \
+        }
+        int it = 0;
+        for (; it + 3 < ntiles; ++it) GLF_H8_BODY(true, true, true)
+        if (it + 2 < ntiles) { GLF_H8_BODY(true, false, true) ++it; }
+        if (it + 1 < ntiles) { GLF_H8_BODY(false, false, true) ++it; }
+        GLF_H8_BODY(false, false, false)
+    }
+
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    auto emit = [&](const f32x16& acc, int ti, int tj) {
+        const int col = tn * BN + wn + 32 * tj + col_l;
+        if (col >= pN) return;
+        const float bv = p_bias ? p_bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * BM8 + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
+            if (row < pMe) {
+                if (p_rect) {
+                    const int hw = r_h * r_w;
+                    const int n = row / hw, rem = row - n * hw;
+                    const int yy = rem / r_w;
+                    const long long orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+                    atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
+                } else {
+                    float* dst = C + (long long)row * p_ldc + col;
+                    float v = p_alpha * acc[r] + bv;
+                    if (p_accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    };
+    emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
+    emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// tn kernel: C_tap[m][n] (+)= alpha * sum_{r in slice} A[arow(r)][m] * B[src(r,tap)][n]
+// planes [r][128 cols] with 320-byte rows, fragments transposed on the fly by ds_read_b64_tr_b16.
+// ----------------------------------------------------------------------------------------------------------
+constexpr int RST = 320;
+constexpr int PLANE_T = 32 * RST;
+constexpr int OPER_T = 2 * PLANE_T;
+constexpr size_t SMEM_TN_H = 2 * OPER_T + 32 * sizeof(int);
+
+template <bool GATHER>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArgs args) {
+    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
+    const int p_accumulate = args.accumulate, p_split = args.split;
+    const int p_tiles_n = args.tiles_n;
+    const unsigned p_tap_mask = args.tap_mask;
+    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B;
+    float* __restrict__ p_C = args.C;
+    const float* __restrict__ p_zero = args.zeros;
+    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
+    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
+    float sc_a, sc_b, inv_a, inv_b;
+    pow2_scale(args.amax_a, sc_a, inv_a);
+    pow2_scale(args.amax_b, sc_b, inv_b);
+    const float p_alpha = args.alpha * inv_a * inv_b;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    unsigned char* As = smem_s;
+    unsigned char* Bs = smem_s + OPER_T;
+    int* vflag = reinterpret_cast<int*>(smem_s + 2 * OPER_T);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
+    int tap;
+    {
+        unsigned mm = p_tap_mask;
+        for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
+        tap = __ffs(mm) - 1;
+    }
+    const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
+    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+
+    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
+    if (p_rect) {
+        int y0, y1, x0, x1;
+        tap_rect(1, tap, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
+        r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
+        pKe = g_nimg * r_h * r_w;
+    }
+    int chunk = (pKe + p_split - 1) / p_split;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    const int r0 = sl * chunk;
+    const int r1 = min(pKe, r0 + chunk);
+    if (r0 >= r1) return;
+
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int m0 = tm * BM + 4 * c4, n0 = tn * BN + 4 * c4;
+    const int m0c = min(m0, pM - 4), n0c = min(n0, pN - 4);
+    const int hw = GATHER ? r_h * r_w : 1;
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};
+    float4 ra[4], rb[4];
+    int rvalid[4];
+
+    auto load_tile = [&](int rbase) __attribute__((always_inline)) {
+        long long src[4], arow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rbase + rr + 8 * j;
+            src[j] = -1;
+            arow[j] = min(r, r1 - 1);
+            if (GATHER) {
+                const int rc = min(r, r1 - 1);
+                const int n = rc / hw, rem = rc - n * hw;
+                const int yy = rem / r_w;
+                const int y = r_y0 + yy, x = r_x0 + rem - yy * r_w;
+                arow[j] = ((long long)n * g_hd + y) * g_wd + x;
+                if (r < r1) src[j] = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, n, y, x, tap);
+            } else if (r < r1) {
+                src[j] = r;
+            }
+            rvalid[j] = src[j] >= 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // rows beyond the slice / in the conv padding and the column overhang read the zero page
+            ra[j] = *reinterpret_cast<const float4*>((src[j] >= 0 && m0 < pM ? A + arow[j] * p_lda : p_zero) + m0c);
+            rb[j] = *reinterpret_cast<const float4*>((src[j] >= 0 && n0 < pN ? B + src[j] * p_ldb : p_zero) + n0c);
+        }
+    };
+#define GLF_HT_STORE(J)                                                                                    \
+    {                                                                                                      \
+        const SplitH sa = split4h(ra[J], sc_a);                                                            \
+        const SplitH sb = split4h(rb[J], sc_b);                                                            \
+        unsigned char* da = As + (rr + 8 * J) * RST + c4 * 8;                                              \
+        unsigned char* db = Bs + (rr + 8 * J) * RST + c4 * 8;                                              \
+        *reinterpret_cast<f16x4*>(da) = sa.h; *reinterpret_cast<f16x4*>(da + PLANE_T) = sa.l;              \
+        *reinterpret_cast<f16x4*>(db) = sb.h; *reinterpret_cast<f16x4*>(db + PLANE_T) = sb.l;              \
+        if (c4 == 0) vflag[rr + 8 * J] = rvalid[J];                                                        \
+    }
+
+    // transposing fragment read (see gemm_bf16s.hip): group g of 16 lanes: columns 16*(g&1).., k half g>>1
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int tr_off = (8 * (grp >> 1) + q) * RST + (16 * (grp & 1) + 4 * pp) * 2;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#define GLF_HTR_FRAG(base, dst)                                                                             \
+    {                                                                                                       \
+        const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));                       \
+        const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((base) + 4 * RST));          \
+        typedef short s16x8_ __attribute__((ext_vector_type(8)));                                           \
+        const s16x8_ both_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        dst = __builtin_bit_cast(f16x8, both_);                                                             \
+    }
+
+    load_tile(r0);
+    for (int rbase = r0; rbase < r1; rbase += BK) {
+        GLF_HT_STORE(0) GLF_HT_STORE(1) GLF_HT_STORE(2) GLF_HT_STORE(3)
+        __syncthreads();
+        if (rbase + BK < r1) load_tile(rbase + BK);
+        const bool any = __ballot(vflag[lane & 31] != 0) != 0ull;
+        if (any) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char* ab = As + s * 16 * RST + wm * 2 + tr_off;
+                const unsigned char* bb = Bs + s * 16 * RST + wn * 2 + tr_off;
+                f16x8 b0h, b0l, b1h, b1l;
+                GLF_HTR_FRAG(bb, b0h) GLF_HTR_FRAG(bb + 64, b1h) GLF_HTR_FRAG(bb + PLANE_T, b0l) GLF_HTR_FRAG(bb + 64 + PLANE_T, b1l)
+                {
+                    f16x8 ah, al;
+                    GLF_HTR_FRAG(ab, ah) GLF_HTR_FRAG(ab + PLANE_T, al)
+                    GLF_ROW3(c00, c01, m00, m01, ah, al, b0h, b0l, b1h, b1l)
+                }
+                {
+                    f16x8 ah, al;
+                    GLF_HTR_FRAG(ab + 64, ah) GLF_HTR_FRAG(ab + 64 + PLANE_T, al)
+                    GLF_ROW3(c10, c11, m10, m11, ah, al, b0h, b0l, b1h, b1l)
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const bool atomic = (p_split > 1) || p_accumulate;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    auto emit = [&](const f32x16& acc, int ti, int tj) {
+        const int col = tn * BN + wn + 32 * tj + col_l;
+        if (col >= pN) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
+            if (row < pM) {
+                float* dst = C + (long long)row * p_ldc + col;
+                const float v = p_alpha * acc[r];
+                if (atomic) atomicAdd(dst, v); else *dst = v;
+            }
+        }
+    };
+    emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
+    emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+}
+
+// max |x| over a [rows, cols] view (row stride ld) -> *out (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long rows, int cols, long long ld,
+                                                   int vec, unsigned* __restrict__ out) {
+    const int c4n = vec ? cols >> 2 : 0;
+    const long long total4 = rows * c4n;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    const int tail = cols - 4 * c4n;
+    if (tail) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * tail; i += (long long)gridDim.x * blockDim.x) {
+            const long long r = i / tail;
+            m = fmaxf(m, fabsf(x[r * ld + (cols - tail) + (int)(i - r * tail)]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
+}  // namespace
+
+namespace glf {
+
+int init_gemm_f16s_attrs() {
+    hipError_t e;
+#define SET_ATTR(fn, bytes)                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
+    SET_ATTR((gemm_rows_f16s8_kernel<false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_tn_f16s_kernel<false>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s_kernel<true>), SMEM_TN_H)
+#undef SET_ATTR
+    return GLF_OK;
+}
+
+// Eligibility: the aligned fast path, and every row that can be redirected to the zero page must fit into it.
+bool f16s_rows_ok(const GemmArgs& a) {
+    return a.vec_a && a.vec_b && (a.K % BK) == 0 && a.K >= BK && a.K <= ZERO_PAGE_FLOATS && zero_page() != nullptr;
+}
+bool f16s_tn_ok(const GemmArgs& a) {
+    return a.vec_a && a.vec_b && (a.M % 4) == 0 && (a.N % 4) == 0 && a.M >= 4 && a.N >= 4 &&
+           a.M <= ZERO_PAGE_FLOATS && a.N <= ZERO_PAGE_FLOATS && zero_page() != nullptr;
+}
+
+int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) {
+    GemmArgs a = a0;
+    a.zeros = zero_page();
+    long long tiles_m = (a.M + BM8 - 1) / BM8;
+    if (a.rect) {
+        tiles_m = 0;
+        for (unsigned mm = a.tap_mask; mm; mm &= mm - 1) {
+            const int t = __builtin_ctz(mm);
+            int y0, y1, x0, x1;
+            tap_rect(a.gather, t, a.g.kw, a.g.pad, a.g.dil, a.g.hs, a.g.ws, a.g.hd, a.g.wd, y0, y1, x0, x1);
+            tiles_m += ((long long)a.g.n_img * (y1 - y0) * (x1 - x0) + BM8 - 1) / BM8;
+        }
+    }
+    a.tiles_m = (int)tiles_m;
+    dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
+    if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    return check_launch("gemm_nt(f16x3, 256x128)");
+}
+
+int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) {
+    GemmArgs a = a0;
+    a.zeros = zero_page();
+    if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+    else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+    return check_launch("gemm_tn(f16x3)");
+}
+
+// *out = max(*out, max |x|): out must hold a non-negative float (0 to start a fresh maximum)
+int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s) {
+    const long long total4 = rows * (long long)(vec && (cols >> 2) > 0 ? (cols >> 2) : cols);
+    long long blocks = (total4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, cols, ld, vec, reinterpret_cast<unsigned*>(out));
+    return check_launch("amax");
+}
+
+}  // namespace glf

@@ -591,9 +591,52 @@ int init_gemm_attrs() {
     SET_ATTR((gemm_tn_kernel<false>), SMEM_TN)
     SET_ATTR((gemm_tn_kernel<true>), SMEM_TN)
 #undef SET_ATTR
-    return init_gemm_bf16s_attrs();
+    if (int rc = init_gemm_bf16s_attrs()) return rc;
+    return init_gemm_f16s_attrs();
 }
 }  // namespace glf
+
+namespace {
+// f16x3 with amax_a / amax_b == NULL: measure the operands (exactly the elements the call can read) first
+int self_amax(GemmArgs& a, const glf_gemm_params* p, bool tn, hipStream_t s) {
+    if (a.amax_a && a.amax_b) return GLF_OK;
+    float* slots = glf::amax_scratch(2);
+    GLF_REQUIRE(slots != nullptr, GLF_ERR_WORKSPACE, "gemm(f16x3): no amax scratch");
+    hipError_t e = hipMemsetAsync(slots, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return glf::fail(GLF_ERR_LAUNCH, "hipMemsetAsync(amax): %s", hipGetErrorString(e));
+    const long long src_rows = p->gather ? (long long)p->n_img * p->hs * p->ws : 0;
+    for (int b = 0; b < p->batch; ++b) {
+        if (!a.amax_a) {
+            const long long rows = tn ? p->K : (p->gather ? src_rows : p->M);
+            const int cols = tn ? p->M : p->K;
+            if (int rc = glf::launch_amax(a.A + b * a.bsa, rows, cols, p->lda, a.vec_a, slots, s)) return rc;
+        }
+        if (!a.amax_b) {
+            if (tn) {
+                const long long rows = p->gather ? src_rows : p->K;
+                if (int rc = glf::launch_amax(a.B + b * a.bsb, rows, p->N, p->ldb, a.vec_b, slots + 1, s)) return rc;
+            } else {
+                for (unsigned mm = p->tap_mask; mm; mm &= mm - 1) {
+                    const int t = __builtin_ctz(mm);
+                    if (int rc = glf::launch_amax(a.B + b * a.bsb + t * a.tap_stride_b, p->N, p->K, p->ldb, a.vec_b, slots + 1, s)) return rc;
+                }
+            }
+        }
+    }
+    if (!a.amax_a) a.amax_a = slots;
+    if (!a.amax_b) a.amax_b = slots + 1;
+    return GLF_OK;
+}
+}  // namespace
+
+extern "C" int glf_amax(const float* x, int64_t rows, int cols, int64_t ld, float* out, glf_stream_t stream) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && out, GLF_ERR_NULL, "amax: null argument");
+    GLF_REQUIRE(rows > 0 && cols > 0 && ld >= cols, GLF_ERR_BAD_SHAPE, "amax: bad extents");
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), glf::S(stream));
+    if (e != hipSuccess) return glf::fail(GLF_ERR_LAUNCH, "hipMemsetAsync(amax): %s", hipGetErrorString(e));
+    return glf::launch_amax(x, rows, cols, ld, aligned16(x) && (ld % 4 == 0), out, glf::S(stream));
+}
 
 extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, float* C,
                            const glf_gemm_params* p, glf_stream_t stream) {
@@ -610,6 +653,10 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
     if (glf::precision() == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
+    if (glf::precision() == 2 && glf::f16s_rows_ok(a)) {
+        if (int rc = self_amax(a, p, false, glf::S(stream))) return rc;
+        return glf::launch_rows_f16s(a, grid, p->gather != 0, glf::S(stream));
+    }
     if (p->gather)
         hipLaunchKernelGGL((gemm_rows_kernel<0, true>), grid, dim3(NTHREADS), SMEM_ROWS_NT, glf::S(stream), a);
     else
@@ -658,6 +705,10 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
     }
     dim3 grid(a.tiles_m * a.tiles_n, ntap, p->batch * a.split);
     if (glf::precision() == 1 && glf::bf16s_tn_ok(a)) return glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
+    if (glf::precision() == 2 && glf::f16s_tn_ok(a)) {
+        if (int rc = self_amax(a, p, true, glf::S(stream))) return rc;
+        return glf::launch_tn_f16s(a, grid, p->gather != 0, glf::S(stream));
+    }
     if (p->gather)
         hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
     else

@@ -191,8 +191,24 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, float ep
 }
 
 // ---- streaming applies ------------------------------------------------------------------
+// by-product of the applies for the f16x3 contraction kernels: max |value written|, one atomic per block
+// (*amax_out must hold a non-negative float, normally 0, before the launch)
+__device__ __forceinline__ void block_amax(float m, float* __restrict__ amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res, int ldr,
-                                                       float* __restrict__ y, int ldy, Coef k, long long total4, int c4, int relu) {
+                                                       float* __restrict__ y, int ldy, Coef k, long long total4, int c4, int relu,
+                                                       float* __restrict__ amax_out) {
+    float am = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
@@ -209,7 +225,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax_out) block_amax(am, amax_out);
 }
 
 // dx = gamma*invstd*(dy' - [sum_dy/n + xhat*sum_dyx/n]) ; dres = dy'
@@ -217,7 +235,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, int ldy, Coef k,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
-                                                           long long total4, int c4, int relu, int training, float inv_n) {
+                                                           long long total4, int c4, int relu, int training, float inv_n,
+                                                           float* __restrict__ amax_out) {
+    float am = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
@@ -244,7 +264,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o = make_float4(g.x * ga.x * is.x, g.y * ga.y * is.y, g.z * ga.z * is.z, g.w * ga.w * is.w);
         }
         *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax_out) block_amax(am, amax_out);
 }
 
 // ---- TPAVI tail: one wavefront per row ---------------------------------------------------
@@ -390,7 +412,7 @@ extern "C" int glf_bn_eval_coeffs(const float* rm, const float* rv, float eps, f
 
 extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                            int rows, int c, int relu, glf_stream_t s) {
+                            int rows, int c, int relu, float* amax_out, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply: null argument");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply: rows must be > 0");
@@ -398,14 +420,14 @@ extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int 
     if (residual) { REQ_AL(residual, "residual"); REQ_LD(ldr, "ldr"); }
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), x, ldx, residual, ldr, y, ldy,
-                       Coef{mean, invstd, gamma, beta}, total4, c / 4, relu);
+                       Coef{mean, invstd, gamma, beta}, total4, c / 4, relu, amax_out);
     return glf::check_launch("bn_apply");
 }
 
 extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* gamma,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-                          int rows, int c, int relu, int training, double* workspace, glf_stream_t s) {
+                          int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
     GLF_REQUIRE(!relu || y, GLF_ERR_NULL, "bn_bwd: y is required when relu != 0");
@@ -424,7 +446,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
                        Coef{mean, invstd, gamma, nullptr}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
-                       1.0f / (float)rows);
+                       1.0f / (float)rows, amax_out);
     return glf::check_launch("bn_bwd_apply");
 }
 

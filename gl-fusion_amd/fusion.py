@@ -20,7 +20,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import check, lib
-from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, colsum, gemm, split_mode, transpose2d, weight_T
+from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, amax_of, colsum, gemm, split_mode, transpose2d, weight_T
 
 
 class TpaviFn(Function):
@@ -45,7 +45,9 @@ class TpaviFn(Function):
         bcat = torch.cat((th_b.detach(), ph_b.detach(), g_b.detach()), dim=0)
         c3 = 3 * ci
         qkv = torch.empty(rows, c3, **f32)
-        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat)
+        am_x = amax_of(x)
+        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=amax_of(Wcat))
+        am_q = amax_of(qkv)                  # one bound for the theta | phi | g column slices
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
         bq = L * c3                                                          # batch (frame) stride inside qkv
 
@@ -53,23 +55,25 @@ class TpaviFn(Function):
         if mode == "dot":
             att = torch.empty(n, ci, ci, **f32)                              # M_n = phi_n^T g_n / L
             gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=c3, ldb=c3, ldc=ci, batch=n, bsa=bq, bsb=bq,
-                 bsc=ci * ci, alpha=1.0 / L)
+                 bsc=ci * ci, alpha=1.0 / L, amax_a=am_q, amax_b=am_q)
             if split_mode() and ci % 32 == 0:      # y_n = theta_n M_n as NT against M_n^T (split-bf16 kernels are NT / TN only)
                 attT = transpose2d(att, ci, ci, n)
-                gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
+                gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci,
+                     amax_a=am_q, amax_b=amax_of(attT))
                 del attT
             else:
                 gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
         elif mode == "embedded":
             att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T)
-            gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=c3, ldb=c3, ldc=L, batch=n, bsa=bq, bsb=bq, bsc=L * L)
+            gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=c3, ldb=c3, ldc=L, batch=n, bsa=bq, bsb=bq, bsc=L * L,
+                 amax_a=am_q, amax_b=am_q)
             check(lib.glf_softmax_rows(_p(att), n * L, L, _stream()), "softmax_rows")
             gemm("nn", att, g, y, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=ci, batch=n, bsa=L * L, bsb=bq, bsc=L * ci)
         else:
             raise RuntimeError(f"TPAVI mode {mode!r} is not on the path (built: 'dot', 'embedded')")
 
         wz = torch.empty(rows, c, **f32)
-        gemm("nt", y, zW, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b)
+        gemm("nt", y, zW, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=amax_of(y), amax_b=amax_of(zW))
 
         mean = torch.empty(c, **f32)
         invstd = torch.empty(c, **f32)
@@ -112,17 +116,18 @@ class TpaviFn(Function):
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), None, _stream()), "bn_bwd")
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)
         dzW = (torch.empty if sp == 1 else torch.zeros)(c, ci, **f32)
-        gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp)
+        am_dwz, am_q = amax_of(dwz), amax_of(qkv)
+        gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=amax_of(y))
         dzb = colsum(dwz, rows, c)
         split = split_mode() and ci % 32 == 0 and c % 32 == 0
         (wz_o,) = ctx.owners
         dy = torch.empty(rows, ci, **f32)
         if split:
-            gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci)
+            gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=amax_of(zW))
         else:
             gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
         del dwz
@@ -130,40 +135,50 @@ class TpaviFn(Function):
         dqkv = torch.empty(rows, c3, **f32)                   # [d theta | d phi | d g], row stride 3*ci
         dth, dph, dg = dqkv[:, 0:ci], dqkv[:, ci:2 * ci], dqkv[:, 2 * ci:]
         bs = L * ci
+        am_dy = amax_of(dy)
         if mode == "dot":
             # y_n = th_n M_n ;  M_n = ph_n^T g_n / L
-            gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=c3, batch=n, bsa=bs, bsb=ci * ci, bsc=bq)
+            gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=c3, batch=n, bsa=bs, bsb=ci * ci, bsc=bq,
+                 amax_a=am_dy, amax_b=amax_of(att))
             dM = torch.empty(n, ci, ci, **f32)
-            gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=bs, bsc=ci * ci)
-            gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+            gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=bs, bsc=ci * ci,
+                 amax_a=am_q, amax_b=am_dy)
+            am_dM = amax_of(dM)
+            gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L,
+                 amax_a=am_q, amax_b=am_dM)
             if split:
                 dMT = transpose2d(dM, ci, ci, n)
-                gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+                gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L,
+                     amax_a=am_q, amax_b=am_dM)
                 del dMT
             else:
                 gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
         else:
             # y_n = P_n g_n ; P_n = softmax(th_n ph_n^T)
             dP = torch.empty(n, L, L, **f32)
-            gemm("nt", dy, g, dP, M=L, N=L, K=ci, lda=ci, ldb=c3, ldc=L, batch=n, bsa=bs, bsb=bq, bsc=L * L)
-            gemm("tn", att, dy, dg, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=c3, batch=n, bsa=L * L, bsb=bs, bsc=bq)
+            gemm("nt", dy, g, dP, M=L, N=L, K=ci, lda=ci, ldb=c3, ldc=L, batch=n, bsa=bs, bsb=bq, bsc=L * L,
+                 amax_a=am_dy, amax_b=am_q)
+            gemm("tn", att, dy, dg, M=L, N=ci, K=L, lda=L, ldb=ci, ldc=c3, batch=n, bsa=L * L, bsb=bs, bsc=bq,
+                 amax_a=amax_of(att), amax_b=am_dy)
             check(lib.glf_softmax_rows_bwd(_p(att), _p(dP), n * L, L, _stream()), "softmax_rows_bwd")   # dP <- dS
             gemm("nn", dP, ph, dth, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=c3, batch=n, bsa=L * L, bsb=bq, bsc=bq)
-            gemm("tn", dP, th, dph, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=c3, batch=n, bsa=L * L, bsb=bq, bsc=bq)
+            gemm("tn", dP, th, dph, M=L, N=ci, K=L, lda=L, ldb=c3, ldc=c3, batch=n, bsa=L * L, bsb=bq, bsc=bq,
+                 amax_a=amax_of(dP), amax_b=am_q)
             del dP
         del dy
 
         # the three projections as one: qkv = x Wcat^T + bcat
         sp = _tn_split(rows, c3, c, 1)
         dWcat = (torch.empty if sp == 1 else torch.zeros)(c3, c, **f32)
-        gemm("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp)
+        am_dq = amax_of(dqkv)
+        gemm("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp, amax_a=am_dq, amax_b=amax_of(x))
         dbcat = colsum(dqkv, rows, c3)
         grads_w = [dWcat[i * ci:(i + 1) * ci].reshape(pshape) for i in range(3)]
         grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
         dx = du                                              # residual gradient, accumulated in place (one RMW)
         if split:
             WcatT = transpose2d(Wcat, c3, c).view(c, c3)
-            gemm("nt", dqkv, WcatT, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True)
+            gemm("nt", dqkv, WcatT, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=amax_of(Wcat))
         else:
             gemm("nn", dqkv, Wcat, dx, M=rows, N=c, K=c3, lda=c3, ldb=c, ldc=c, accumulate=True)
         dx = dx.view_as(x)

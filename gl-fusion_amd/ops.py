@@ -114,8 +114,10 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          lda: int, ldb: int, ldc: int, bias: Optional[torch.Tensor] = None, taps: int = 1, mask: int = 1,
          tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
-         split: int = 1, rect: bool = False) -> None:
-    """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil)."""
+         split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
+         amax_b: Optional[torch.Tensor] = None) -> None:
+    """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
+    amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library)."""
     p = GemmParams()
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
     p.taps, p.tap_mask, p.tap_stride_b, p.gather = taps, mask, tap_stride_b, gather
@@ -125,6 +127,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
     p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
     p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
+    p.amax_a, p.amax_b = _p(amax_a), _p(amax_b)
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -145,6 +148,53 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         dense = 2.0 * M * N * K * taps * batch
         prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * bin(mask).count("1") / taps, ev0, ev1,
                      (M, N, K, taps, bin(mask).count("1"), batch, split, geo[8] if geo else 0, geo[9] if geo else 0)))
+
+
+def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Device scalar max|t| for the f16x3 contraction kernels (None under the other precisions, where it is not
+    used).  Measured once per tensor and version and remembered on the tensor object; a permutation of the
+    elements (weight re-layouts) has the same maximum, so callers pass the owning parameter.  Only call it on
+    tensors whose contents are final (raw kernel writes do not bump torch's version counter)."""
+    if t is None or int(lib.glf_get_precision()) != 2:
+        return None
+    hit = getattr(t, "_glf_amax", None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        return hit[2]
+    out = torch.empty(1, dtype=torch.float32, device=t.device)
+    if t.is_contiguous():
+        check(lib.glf_amax(_p(t), 1, t.numel(), t.numel(), _p(out), _stream()), "amax")
+    elif t.dim() == 2 and t.stride(1) == 1:
+        check(lib.glf_amax(_p(t), t.shape[0], t.shape[1], t.stride(0), _p(out), _stream()), "amax")
+    else:
+        return None                      # the library measures the operand region itself
+    try:
+        t._glf_amax = (t._version, t.data_ptr(), out)
+    except AttributeError:
+        pass
+    return out
+
+
+_amax_pool = [None, 0]
+
+
+def amax_slot(dev) -> Optional[torch.Tensor]:
+    """A zeroed device float for a kernel that reports max|output| as a by-product (None unless f16x3 is
+    active).  Slots come from a pre-zeroed pool (one fill kernel per 4096 slots); a used-up pool stays alive
+    through the slices that reference it."""
+    if int(lib.glf_get_precision()) != 2:
+        return None
+    if _amax_pool[0] is None or _amax_pool[1] >= 4096 or _amax_pool[0].device != dev:
+        _amax_pool[0] = torch.zeros(4096, dtype=torch.float32, device=dev)
+        _amax_pool[1] = 0
+    i = _amax_pool[1]
+    _amax_pool[1] = i + 1
+    return _amax_pool[0][i:i + 1]
+
+
+def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
+    """Attach a maximum produced as a by-product of the kernel that wrote t."""
+    if amax is not None:
+        t._glf_amax = (t._version, t.data_ptr(), amax)
 
 
 def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
@@ -171,8 +221,8 @@ def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
 
 
 def split_mode() -> bool:
-    """True when contractions run on the split-bf16 (bf16x6) kernels."""
-    return int(lib.glf_get_precision()) == 1
+    """True when contractions run on a split (bf16x6 / f16x3) kernel family, which has NT and TN forms only."""
+    return int(lib.glf_get_precision()) >= 1
 
 
 def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.Tensor:
@@ -290,7 +340,8 @@ class Conv2dFn(Function):
         if rect:
             y.zero_()
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
-             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect)
+             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
+             amax_a=amax_of(x), amax_b=amax_of(weight))
         ctx.save_for_backward(x, wt)
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
@@ -305,6 +356,7 @@ class Conv2dFn(Function):
         taps = kh * kw
         rows_o = n * ho * wo
         dx = dw = db = None
+        am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
         if ctx.needs_input_grad[0]:
             mask = 1 if plain else tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
             if mask == 0:
@@ -317,7 +369,8 @@ class Conv2dFn(Function):
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
                     gemm("nt", dy, tap_major_T(ctx.weight_ref), dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                          taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
-                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
+                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect,
+                         amax_a=am_dy, amax_b=am_w)
                 else:
                     gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                          tap_stride_b=cout * cin, gather=0 if plain else 2,
@@ -333,7 +386,8 @@ class Conv2dFn(Function):
             dwt = (torch.empty if (split == 1 and full) else torch.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
             gemm("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
-                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect)
+                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,
+                 amax_a=am_dy, amax_b=amax_of(x))
             if taps == 1:
                 dw = dwt.view(wshape)
             else:
@@ -363,7 +417,8 @@ class ConvCatFn(Function):
         off = 0
         for i, t in enumerate(xs):
             ck = t.shape[-1]
-            gemm("nt", t, w2[:, off:], y, M=rows, N=cout, K=ck, lda=ck, ldb=ctot, ldc=cout, accumulate=i > 0)
+            gemm("nt", t, w2[:, off:], y, M=rows, N=cout, K=ck, lda=ck, ldb=ctot, ldc=cout, accumulate=i > 0,
+                 amax_a=amax_of(t), amax_b=amax_of(weight))
             off += ck
         if off != ctot:
             raise RuntimeError(f"conv_cat: inputs have {off} channels in total, weight expects {ctot}")
@@ -385,20 +440,22 @@ class ConvCatFn(Function):
             dw = (torch.empty if split == 1 else torch.zeros)(cout, ctot, dtype=torch.float32, device=dy.device)
         grads = []
         off = 0
+        am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
         for i, t in enumerate(xs):
             ck = t.shape[-1]
             if ctx.needs_input_grad[1 + i]:
                 dx = torch.empty_like(t)
                 if split_mode() and cout % 32 == 0:
                     wT = weight_T(w2, ctx.weight_ref)                     # [ctot][cout]
-                    gemm("nt", dy, wT[off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=cout, ldc=ck)
+                    gemm("nt", dy, wT[off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=cout, ldc=ck, amax_a=am_dy, amax_b=am_w)
                 else:
                     gemm("nn", dy, w2[:, off:], dx, M=rows, N=ck, K=cout, lda=cout, ldb=ctot, ldc=ck)
                 grads.append(dx)
             else:
                 grads.append(None)
             if dw is not None:
-                gemm("tn", dy, t, dw[:, off:], M=cout, N=ck, K=rows, lda=cout, ldb=ck, ldc=ctot, split=split)
+                gemm("tn", dy, t, dw[:, off:], M=cout, N=ck, K=rows, lda=cout, ldb=ck, ldc=ctot, split=split,
+                     amax_a=am_dy, amax_b=amax_of(t))
             off += ck
         return (dw.view(ctx.wshape) if dw is not None else None, *grads)
 
@@ -466,8 +523,10 @@ class BatchNormActFn(Function):
         if residual is not None:
             residual = _contig(_chk(residual, "bn residual"))
         y = torch.empty_like(x)
+        am = amax_slot(dev)
         check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
-                               int(relu), _stream()), "bn_apply")
+                               int(relu), _p(am), _stream()), "bn_apply")
+        set_amax(y, am)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.cfg = (rows, c, relu, training, residual is not None)
         return y
@@ -483,8 +542,10 @@ class BatchNormActFn(Function):
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        am = amax_slot(dev)
         check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(dx), c, _p(dres), c,
-                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _stream()), "bn_bwd")
+                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), _stream()), "bn_bwd")
+        set_amax(dx, am)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
@@ -855,11 +916,13 @@ def overlap_metrics_from_counts(counts: torch.Tensor, eps: float = 1e-5):
 
 
 # ----------------------------------------------------------------------------------------
-# contraction precision (process-wide): "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 emulation
+# contraction precision (process-wide): "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
+# "f16x3" = scaled split-fp16 (3 MFMAs per product)
+PRECISIONS = ("f32", "bf16x6", "f16x3")
 # ----------------------------------------------------------------------------------------
 def set_precision(mode: str) -> None:
-    check(lib.glf_set_precision({"f32": 0, "bf16x6": 1}[mode]), "set_precision")
+    check(lib.glf_set_precision(PRECISIONS.index(mode)), "set_precision")
 
 
 def get_precision() -> str:
-    return ("f32", "bf16x6")[int(lib.glf_get_precision())]
+    return PRECISIONS[int(lib.glf_get_precision())]

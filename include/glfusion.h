@@ -50,7 +50,12 @@ int glf_init(void);
  *   1 = split-bf16 "bf16x6": each fp32 operand is split into three bf16 pieces and six
  *       v_mfma_f32_32x32x16_bf16 reproduce the fp32 product to 2^-23 (fp32 accumulate) -- fp32-equivalent
  *       results at 2.67x the fp32-MFMA roof.  Calls that miss the aligned fast path (and glf_gemm_nn) stay
- *       on the exact kernels. */
+ *       on the exact kernels;
+ *   2 = split-fp16 "f16x3": each operand is scaled by a power of two taken from its max magnitude
+ *       (glf_gemm_params.amax_a / amax_b) and split into two fp16 pieces; three
+ *       v_mfma_f32_32x32x16_f16 reproduce the fp32 product to 2^-22 relative to the operand maxima
+ *       (fp32 accumulate) at 5.3x the fp32-MFMA roof.  Elements more than 2^27 below their operand's
+ *       maximum keep an absolute (not relative) error bound, 2^-49 of that maximum.  Same fast-path rule. */
 int glf_set_precision(int mode);
 int glf_get_precision(void);
 /* sizeof(glf_gemm_params) as compiled into the library (binding self-check). */
@@ -89,7 +94,14 @@ typedef struct {
                                 /* GEMM over exactly its in-range rectangle of pixels; nt/nn sum  */
                                 /* the taps with float atomics into a ZERO-FILLED C (no bias); tn */
                                 /* shortens each tap's reduction to its rectangle                 */
+    const float* amax_a;        /* precision 2 only: DEVICE scalars holding an upper bound of max|A| */
+    const float* amax_b;        /* and max|B| over the elements the call reads (glf_amax, or the     */
+                                /* kernel that produced the operand).  NULL: the library measures    */
+                                /* the operand itself first (one extra read of it).                  */
 } glf_gemm_params;
+
+/* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
+int glf_amax(const float* x, int64_t rows, int cols, int64_t ld, float* out, glf_stream_t stream);
 
 /* A[m][k] (k contiguous, rows gathered per `gather`), B_tap[n][k] (k contiguous: torch's
  * [Cout][Cin] weight layout per tap), C[m][n].  Replaces F.conv2d / nn.Conv3d(1x1x1) forward:
@@ -143,19 +155,22 @@ int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps, float mome
                  int64_t* num_batches_tracked /* may be NULL; += 1 */,
                  double* workspace, glf_stream_t s);
 /* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  For eval() pass running_mean and
- * 1/sqrt(running_var+eps) (glf_bn_eval_coeffs).  In-place (y == x) allowed. */
+ * 1/sqrt(running_var+eps) (glf_bn_eval_coeffs).  In-place (y == x) allowed.
+ * amax_out (may be NULL): device float that must hold 0 (or any lower bound) before the call and
+ * receives max(*amax_out, max|y|) -- the operand maximum the f16x3 contractions need, for free. */
 int glf_bn_eval_coeffs(const float* running_mean, const float* running_var, float eps,
                        float* mean, float* invstd, int c, glf_stream_t s);
 int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                  const float* mean, const float* invstd, const float* gamma, const float* beta,
-                 int rows, int c, int relu, glf_stream_t s);
+                 int rows, int c, int relu, float* amax_out, glf_stream_t s);
 /* Backward.  y is the forward output (ReLU mask = y > 0) and may be NULL when relu == 0.
  * training != 0: full batch-stat backward; training == 0: dx = dy*mask*gamma*invstd.
- * dres (may be NULL) receives dy*mask (gradient of the residual input). */
+ * dres (may be NULL) receives dy*mask (gradient of the residual input).  amax_out: as in
+ * glf_bn_apply, for dx. */
 int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                const float* mean, const float* invstd, const float* gamma,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-               int rows, int c, int relu, int training, double* workspace, glf_stream_t s);
+               int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise pieces of the path.

@@ -29,9 +29,9 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["f32", "bf16x6"])
+@pytest.fixture(params=["f32", "bf16x6", "f16x3"])
 def precision(request):
-    """Runs a GPU test under both contraction precisions: exact fp32 MFMA and split-bf16 (bf16x6)."""
+    """Runs a GPU test under every contraction precision: exact fp32 MFMA, split-bf16 (bf16x6), scaled split-fp16 (f16x3)."""
     from glfusion_amd import ops
     ops.set_precision(request.param)
     yield request.param
