@@ -308,7 +308,18 @@ def rect_fraction(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: 
     return f
 
 
-RECT_THRESHOLD = 0.8     # use rect mode when less than this fraction of the kept taps' work is in range
+# use rect mode when less than this fraction of the kept taps' work is in range (per conv pass)
+# The rectangle GEMMs sum their taps with float atomics; dgrad writes the widest outputs (Cin = 2048 columns for
+# ASPP) over the shortest reductions (Cout = 256), so once the MFMA work is cheap (f16x3) the atomics cost more
+# than the padding work they avoid unless most of it is padding: measured on the ASPP shapes, rate 12 (51 % in
+# range) is faster dense, rate 24 (18 %) faster as rectangles.
+RECT_THRESHOLD = {"fwd": 0.8, "dgrad": 0.8, "wgrad": 0.8, "dgrad_f16x3": 0.35}
+
+
+def _rect_thr(which: str) -> float:
+    if which == "dgrad" and int(lib.glf_get_precision()) == 2:
+        return RECT_THRESHOLD["dgrad_f16x3"]
+    return RECT_THRESHOLD[which]
 
 
 def _conv_out(h: int, k: int, stride: int, pad: int, dil: int) -> int:
@@ -336,7 +347,7 @@ class Conv2dFn(Function):
         geo = (n, h, w, ho, wo, kh, kw, stride, pad, dil)
         mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
         rect = (not plain and taps > 1 and stride == 1 and bias is None and bin(mask).count("1") > 1
-                and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+                and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("fwd"))
         if rect:
             y.zero_()
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
@@ -363,7 +374,7 @@ class Conv2dFn(Function):
                 dx = torch.zeros_like(x)
             else:
                 rect = (not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1
-                        and rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+                        and rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask) < _rect_thr("dgrad"))
                 dx = torch.zeros_like(x) if rect else torch.empty_like(x)
                 if split_mode() and cout % 32 == 0:
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
@@ -379,7 +390,7 @@ class Conv2dFn(Function):
             mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
             ntap = bin(mask).count("1")
             rect = (not plain and taps > 1 and stride == 1 and ntap > 1
-                    and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < RECT_THRESHOLD)
+                    and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("wgrad"))
             frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
             split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
             full = mask == (1 << taps) - 1

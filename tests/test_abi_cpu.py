@@ -39,7 +39,7 @@ def test_gemm_params_struct_matches_header_layout():
         decl = decl.strip()
         if not decl:
             continue
-        parts = decl.split(None, 1)[1]
+        parts = decl.replace("const float*", "ptr").split(None, 1)[1]
         names += [n.strip() for n in parts.split(",")]
     assert names == [f[0] for f in _lib.GemmParams._fields_]
     dll = ctypes.CDLL(_lib.LIB_PATH)
