@@ -490,6 +490,242 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// tn kernel, 8 waves: tile 256 (A columns) x 128 (B columns) x 32 rows, two LDS buffers, the software pipeline of the
+// rows kernel (tile t multiplied out of buffer t&1 while tile t+1 is converted into the other buffer in six pieces
+// between MFMA groups and tile t+2 is in flight from global memory).  Planes are [r][cols] with 576-byte (A) and
+// 320-byte (B) rows: both strides are 16 mod 64 dwords, which keeps the transposing ds_read_b64_tr_b16 fragment
+// reads and the 8-byte staging writes conflict-free.  Row coordinates (n, y, x) advance incrementally by 32 per
+// tile; rows outside the slice, in the conv padding or in the column overhang are loaded from the zero page.
+// Used when M > 128 (otherwise half of the 256-wide tile would be idle and the 128 x 128 kernel above runs).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int TM8 = 256;
+constexpr int RSA = 576, RSB = 320;
+constexpr int PA8 = 32 * RSA, PB8 = 32 * RSB;
+constexpr int TBUF8 = 2 * PA8 + 2 * PB8;
+constexpr size_t SMEM_TN_H8 = 2 * TBUF8;
+
+template <bool GATHER>
+__global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs args) {
+    const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
+    const int p_accumulate = args.accumulate, p_split = args.split;
+    const int p_tiles_n = args.tiles_n;
+    const unsigned p_tap_mask = args.tap_mask;
+    const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B;
+    float* __restrict__ p_C = args.C;
+    const float* __restrict__ p_zero = args.zeros;
+    const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
+    const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;
+    const int g_nimg = args.g.n_img, p_rect = GATHER ? args.rect : 0;
+    float sc_a, sc_b, inv_a, inv_b;
+    pow2_scale(args.amax_a, sc_a, inv_a);
+    pow2_scale(args.amax_b, sc_b, inv_b);
+    const float p_alpha = args.alpha * inv_a * inv_b;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
+    int tap;
+    {
+        unsigned mm = p_tap_mask;
+        for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
+        tap = __ffs(mm) - 1;
+    }
+    const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
+    const float* __restrict__ A = p_A + (long long)bz * p_bsa;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+
+    int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
+    if (p_rect) {
+        int y0, y1, x0, x1;
+        tap_rect(1, tap, g_kw, g_pad, g_dil, g_hs, g_ws, g_hd, g_wd, y0, y1, x0, x1);
+        r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
+        pKe = g_nimg * r_h * r_w;
+    }
+    int chunk = (pKe + p_split - 1) / p_split;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    const int r0 = sl * chunk;
+    const int r1 = min(pKe, r0 + chunk);
+    if (r0 >= r1) return;
+    const int ntiles = (r1 - r0 + BK - 1) / BK;
+
+    // staging map: A tile 32 x 256 floats = 4 float4 per thread (rows ra0 + 8 j, column ca), B tile 32 x 128 = 2 (rows rb0 + 16 j)
+    const int ca = tid & 63, ra0 = tid >> 6;
+    const int cb = tid & 31, rb0 = tid >> 5;
+    const int m0 = tm * TM8 + 4 * ca, n0 = tn * BN + 4 * cb;
+    const bool a_col_ok = m0 < pM, b_col_ok = n0 < pN;
+    const float* __restrict__ Ac = A + (a_col_ok ? m0 : 0);
+    const float* __restrict__ Bc = B + (b_col_ok ? n0 : 0);
+    const float* __restrict__ za = p_zero + (a_col_ok ? m0 : 0);
+    const float* __restrict__ zb = p_zero + (b_col_ok ? n0 : 0);
+
+    // current row index and (for conv gathers) its pixel coordinates inside the rectangle, per staged row
+    int ar[4], an[4], ay[4], ax[4];
+    int br[2], bn[2], by[2], bx[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ar[j] = r0 + ra0 + 8 * j;
+        an[j] = 0; ay[j] = 0; ax[j] = 0;
+        if (GATHER && p_rect) {
+            const int hw = r_h * r_w;
+            const int n = ar[j] / hw, rem = ar[j] - n * hw;
+            const int yy = rem / r_w;
+            an[j] = n; ay[j] = yy; ax[j] = rem - yy * r_w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        br[j] = r0 + rb0 + 16 * j;
+        bn[j] = 0; by[j] = 0; bx[j] = 0;
+        if (GATHER) {
+            const int hw = r_h * r_w;
+            const int n = br[j] / hw, rem = br[j] - n * hw;
+            const int yy = rem / r_w;
+            bn[j] = n; by[j] = yy; bx[j] = rem - yy * r_w;
+        }
+    }
+    const float* pa[4];
+    const float* pb[2];
+    // pointers of the NEXT tile to load, then step every row by 32
+    auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = ar[j] < r1 && a_col_ok;
+            long long arow = ar[j];
+            if (GATHER && p_rect) arow = ((long long)an[j] * g_hd + r_y0 + ay[j]) * g_wd + r_x0 + ax[j];
+            pa[j] = ok ? Ac + arow * p_lda : za;
+            ar[j] += BK;
+            if (GATHER && p_rect) {
+                ax[j] += BK;
+                while (ax[j] >= r_w) { ax[j] -= r_w; ++ay[j]; }
+                while (ay[j] >= r_h) { ay[j] -= r_h; ++an[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            long long src = br[j];
+            bool ok = br[j] < r1 && b_col_ok;
+            if (GATHER) {
+                const int sr = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, bn[j], r_y0 + by[j], r_x0 + bx[j], tap);
+                ok = ok && sr >= 0;
+                src = sr;
+            }
+            pb[j] = ok ? Bc + src * p_ldb : zb;
+            br[j] += BK;
+            if (GATHER) {
+                bx[j] += BK;
+                while (bx[j] >= r_w) { bx[j] -= r_w; ++by[j]; }
+                while (by[j] >= r_h) { by[j] -= r_h; ++bn[j]; }
+            }
+        }
+    };
+
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};
+    float4 ra[4], rb[2];
+    const int st_a = ra0 * RSA + ca * 8, st_b = rb0 * RSB + cb * 8;
+#define GLF_T8_CONV_A(J, buf_)                                                                               \
+    {                                                                                                        \
+        const SplitH s = split4h(ra[J], sc_a);                                                               \
+        unsigned char* d = smem_s + (buf_) * TBUF8 + st_a + J * 8 * RSA;                                     \
+        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PA8) = s.l;                        \
+    }
+#define GLF_T8_CONV_B(J, buf_)                                                                               \
+    {                                                                                                        \
+        const SplitH s = split4h(rb[J], sc_b);                                                               \
+        unsigned char* d = smem_s + (buf_) * TBUF8 + 2 * PA8 + st_b + J * 16 * RSB;                          \
+        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PB8) = s.l;                        \
+    }
+#define GLF_T8_PIECE(pc, buf_, conv_, load_)                                                                 \
+    switch (pc) {                                                                                            \
+        case 0: if (conv_) GLF_T8_CONV_A(0, buf_) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0]); break; \
+        case 1: if (conv_) GLF_T8_CONV_A(1, buf_) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); break; \
+        case 2: if (conv_) GLF_T8_CONV_A(2, buf_) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); break; \
+        case 3: if (conv_) GLF_T8_CONV_A(3, buf_) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); break; \
+        case 4: if (conv_) GLF_T8_CONV_B(0, buf_) if (load_) rb[0] = *reinterpret_cast<const float4*>(pb[0]); break; \
+        default: if (conv_) GLF_T8_CONV_B(1, buf_) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); break; \
+    }
+
+    // transposing fragment reads (see gemm_bf16s.hip): group g of 16 lanes: columns 16*(g&1).., k half g>>1
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int tr_a = (8 * (grp >> 1) + q) * RSA + (16 * (grp & 1) + 4 * pp) * 2 + wm * 2;
+    const int tr_b = (8 * (grp >> 1) + q) * RSB + (16 * (grp & 1) + 4 * pp) * 2 + wn * 2;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#define GLF_T8_FRAG(base, RS_, dst)                                                                         \
+    {                                                                                                       \
+        const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));                       \
+        const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((base) + 4 * RS_));          \
+        typedef short s16x8_ __attribute__((ext_vector_type(8)));                                           \
+        const s16x8_ both_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        dst = __builtin_bit_cast(f16x8, both_);                                                             \
+    }
+
+    // prologue: tile 0 -> buffer 0, tile 1 raw in registers
+    advance();
+#pragma unroll
+    for (int pc = 0; pc < 6; ++pc) { GLF_T8_PIECE(pc, 0, false, true) }
+    {
+        const bool more = ntiles > 1;
+        if (more) advance();
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) { GLF_T8_PIECE(pc, 0, true, more) }
+    }
+    __syncthreads();
+#define GLF_T8_BODY(CONV_, LOAD_)                                                                             \
+    {                                                                                                         \
+        const int buf = it & 1;                                                                               \
+        if (LOAD_) advance();                                                                                 \
+        const unsigned char* ab = smem_s + buf * TBUF8 + tr_a;                                                \
+        const unsigned char* bb = smem_s + buf * TBUF8 + 2 * PA8 + tr_b;                                      \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
+            f16x8 b0h, b0l, b1h, b1l;                                                                         \
+            GLF_T8_FRAG(bb + s * 16 * RSB, RSB, b0h) GLF_T8_FRAG(bb + s * 16 * RSB + 64, RSB, b1h)            \
+            GLF_T8_FRAG(bb + s * 16 * RSB + PB8, RSB, b0l) GLF_T8_FRAG(bb + s * 16 * RSB + 64 + PB8, RSB, b1l) \
+            {                                                                                                 \
+                f16x8 ah, al;                                                                                 \
+                GLF_T8_FRAG(ab + s * 16 * RSA, RSA, ah) GLF_T8_FRAG(ab + s * 16 * RSA + PA8, RSA, al)         \
+                GLF_T8_PIECE(3 * s + 0, buf ^ 1, CONV_, LOAD_)                                                \
+                GLF_ROW3(c00, c01, m00, m01, ah, al, b0h, b0l, b1h, b1l)                                      \
+                GLF_T8_PIECE(3 * s + 1, buf ^ 1, CONV_, LOAD_)                                                \
+            }                                                                                                 \
+            {                                                                                                 \
+                f16x8 ah, al;                                                                                 \
+                GLF_T8_FRAG(ab + s * 16 * RSA + 64, RSA, ah) GLF_T8_FRAG(ab + s * 16 * RSA + 64 + PA8, RSA, al) \
+                GLF_ROW3(c10, c11, m10, m11, ah, al, b0h, b0l, b1h, b1l)                                      \
+                GLF_T8_PIECE(3 * s + 2, buf ^ 1, CONV_, LOAD_)                                                \
+            }                                                                                                 \
+        }                                                                                                     \
+        __syncthreads();                                                                                      \
+    }
+    int it = 0;
+    for (; it + 2 < ntiles; ++it) GLF_T8_BODY(true, true)
+    if (it + 1 < ntiles) { GLF_T8_BODY(true, false) ++it; }
+    GLF_T8_BODY(false, false)
+
+    const bool atomic = (p_split > 1) || p_accumulate;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    auto emit = [&](const f32x16& acc, int ti, int tj) {
+        const int col = tn * BN + wn + 32 * tj + col_l;
+        if (col >= pN) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * TM8 + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
+            if (row < pM) {
+                float* dst = C + (long long)row * p_ldc + col;
+                const float v = p_alpha * acc[r];
+                if (atomic) atomicAdd(dst, v); else *dst = v;
+            }
+        }
+    };
+    emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
+    emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+}
+
 // max |x| over a [rows, cols] view (row stride ld) -> *out (non-negative floats order like their bit patterns)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long rows, int cols, long long ld,
                                                    int vec, unsigned* __restrict__ out) {
@@ -533,6 +769,8 @@ int init_gemm_f16s_attrs() {
     SET_ATTR((gemm_rows_f16s8_kernel<true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_tn_f16s_kernel<false>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s_kernel<true>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s8_kernel<false>), SMEM_TN_H8)
+    SET_ATTR((gemm_tn_f16s8_kernel<true>), SMEM_TN_H8)
 #undef SET_ATTR
     return GLF_OK;
 }
@@ -569,6 +807,13 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) 
 int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) {
     GemmArgs a = a0;
     a.zeros = zero_page();
+    if (a.M > BM) {                     // 256-wide tiles: re-derive the grid
+        a.tiles_m = (a.M + TM8 - 1) / TM8;
+        dim3 g2((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
+        if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+        else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+        return check_launch("gemm_tn(f16x3, 256x128)");
+    }
     if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
     else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
     return check_launch("gemm_tn(f16x3)");

@@ -83,6 +83,12 @@ CONVS = [
     (3, 28, 28, 256, 5, 1, 1, 0, 1, True),         # head output conv (Cout = 5, bias)
     (3, 28, 28, 256, 1, 1, 1, 0, 1, True),         # centerness output conv (Cout = 1, bias)
     (1, 1, 1, 64, 32, 1, 1, 0, 1, False),          # ASPP pooled branch (M = N frames)
+    # Cout > 128: the 256-column wgrad tiles of the split kernels (plain, padded gather, rect mode, stride 2)
+    (2, 14, 14, 64, 192, 1, 1, 0, 1, False),
+    (2, 28, 28, 32, 160, 3, 1, 2, 2, False),
+    (2, 28, 28, 64, 288, 3, 1, 12, 12, False),
+    (2, 28, 28, 32, 132, 3, 1, 24, 24, False),
+    (2, 55, 55, 16, 136, 3, 2, 1, 1, False),
 ]
 
 
