@@ -39,6 +39,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.events = []        # one per gradient copied on a GPU stream (the model runs its views on side streams)
 
 
 class GradAllReducer:
@@ -80,12 +81,21 @@ class GradAllReducer:
                 dist.broadcast(t.data, src, group=self.group)
 
     def _launch(self, b: _Bucket) -> None:
+        if b.events:            # the collective is ordered after the current stream: make that stream wait for every copy
+            cur = torch.cuda.current_stream(b.flat.device)
+            for e in b.events:
+                cur.wait_event(e)
+            b.events = []
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p: torch.nn.Parameter) -> None:
         b, i = self._where[p]
         off = b.offsets[i]
         b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if b.flat.is_cuda:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(b.flat.device))
+            b.events.append(e)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)

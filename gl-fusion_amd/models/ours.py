@@ -87,17 +87,19 @@ class Global_and_Local(nn.Module):
         self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
     # -- encoder (ours.py:1795-1800) -------------------------------------------------------
+    def _encode_view(self, view: str, xv: torch.Tensor) -> torch.Tensor:
+        blk = self.init_block[view]
+        f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
+        f = blk[3].forward_nhwc(f)
+        f = self.layer1[view].forward_nhwc(f)
+        f = self.layer2[view].forward_nhwc(f)
+        f = self.layer3[view].forward_nhwc(f)
+        return self.layer4[view].forward_nhwc(f)
+
     def _encode(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        f4 = {}
-        for view in self.view_num:
-            blk = self.init_block[view]
-            f = conv_bn_act(ops.to_nhwc(x[view]), blk[0], blk[1], relu=True)
-            f = blk[3].forward_nhwc(f)
-            f = self.layer1[view].forward_nhwc(f)
-            f = self.layer2[view].forward_nhwc(f)
-            f = self.layer3[view].forward_nhwc(f)
-            f4[view] = self.layer4[view].forward_nhwc(f)
-        return f4
+        views = list(self.view_num)
+        outs = ops.parallel_sections([lambda v=v: self._encode_view(v, x[v]) for v in views])   # views are independent
+        return dict(zip(views, outs))
 
     def backbone(self, x):
         """ours.py:1749-1773: per-view encoder + classifier, no fusion."""
@@ -110,23 +112,34 @@ class Global_and_Local(nn.Module):
         views = list(self.view_num)
         hw = x[views[0]].shape[-2:]
         ho, wo = int(hw[0]), int(hw[1])
-        f4 = self._encode(x)
-        # M_cls, M_ctr, local features (ours.py:1802-1816)
-        f4_local = {}
-        f4_glob = {}
-        for v in views:
-            fa, fb, fc, f4_glob[v] = ops.fan_out(f4[v], 4)  # classifier / centerness / gate / global fusion
+
+        # per view: encoder, then M_cls, M_ctr and the gated local features (ours.py:1795-1816)
+        def view_section(v):
+            f = self._encode_view(v, x[v])
+            fa, fb, fc, fg, fe = ops.fan_out(f, 5)          # classifier / centerness / gate / global fusion / mask_bb
             cls = self.classifier[v].forward_nhwc(fa)
             ctr = self.centerness[v].forward_nhwc(fb)
-            f4_local[v] = ops.local_gate(cls, ctr, fc, self.center_aware_weight)
-        # global / local cross-view fusion (ours.py:1819-1830)
-        g_out = self.global_attn.forward_nvhwc(ops.stack_views([f4_glob[v] for v in views]))   # [N,V,h,w,C]
-        l_out = self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))
+            return fe, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+
+        secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
+        f4 = {v: s[0] for v, s in zip(views, secs)}
+        f4_glob = {v: s[1] for v, s in zip(views, secs)}
+        f4_local = {v: s[2] for v, s in zip(views, secs)}
+        # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
+        g_out, l_out = ops.parallel_sections([
+            lambda: self.global_attn.forward_nvhwc(ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
+            lambda: self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))])
         fused = ops.add_views(g_out, l_out)                                                     # ours.py:1833-1834
+
+        def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second
+            m = ops.bilinear_up(self.classifier[v].forward_nhwc(fused[i]), ho, wo)              # ours.py:1837-1838
+            mb = ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), ho, wo)                # ours.py:1840-1841
+            return m, mb
+
+        heads = ops.parallel_sections([lambda i=i, v=v: head_section(i, v) for i, v in enumerate(views)])
         mask, mask_bb, f4_g, f4_l = {}, {}, {}, {}
         for i, v in enumerate(views):
             f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)       # == global_conv_feat[:, :, i, :, :]
             f4_l[v] = l_out[:, i].permute(0, 3, 1, 2)
-            mask[v] = ops.bilinear_up(self.classifier[v].forward_nhwc(fused[i]), ho, wo)        # ours.py:1837-1838
-            mask_bb[v] = ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), ho, wo)        # ours.py:1840-1841
+            mask[v], mask_bb[v] = heads[i]
         return mask, mask_bb, f4_g, f4_l

@@ -11,6 +11,7 @@ tensors (== the row-major matrix [N*H*W, C] the kernels see).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -174,21 +175,22 @@ def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return out
 
 
-_amax_pool = [None, 0]
+_amax_pool = {}
 
 
 def amax_slot(dev) -> Optional[torch.Tensor]:
     """A zeroed device float for a kernel that reports max|output| as a by-product (None unless f16x3 is
-    active).  Slots come from a pre-zeroed pool (one fill kernel per 4096 slots); a used-up pool stays alive
-    through the slices that reference it."""
+    active).  Slots come from a pre-zeroed pool per stream (one fill kernel per 4096 slots); a used-up pool stays
+    alive through the slices that reference it."""
     if int(lib.glf_get_precision()) != 2:
         return None
-    if _amax_pool[0] is None or _amax_pool[1] >= 4096 or _amax_pool[0].device != dev:
-        _amax_pool[0] = torch.zeros(4096, dtype=torch.float32, device=dev)
-        _amax_pool[1] = 0
-    i = _amax_pool[1]
-    _amax_pool[1] = i + 1
-    return _amax_pool[0][i:i + 1]
+    key = torch.cuda.current_stream().cuda_stream          # the fill kernel and the users must share a stream
+    pool = _amax_pool.get(key)
+    if pool is None or pool[1] >= 4096 or pool[0].device != dev:
+        pool = _amax_pool[key] = [torch.zeros(4096, dtype=torch.float32, device=dev), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
 
 
 def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
@@ -743,6 +745,71 @@ def fan_out(x: torch.Tensor, k: int):
     if k <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return tuple(x for _ in range(max(k, 1)))
     return FanOutFn.apply(x, k)
+
+
+# ----------------------------------------------------------------------------------------
+# independent sections on side streams
+# ----------------------------------------------------------------------------------------
+# The per-view encoders / heads and the two fusion blocks are independent chains.  Each kernel of a chain either
+# fills the chip with MFMA work in whole "rounds" of 256 workgroups (leaving the last round partly idle) or is a
+# short HBM-bound pass; running the chains on separate HIP streams lets the hardware fill one chain's idle CUs
+# with another chain's workgroups.  Backward nodes run on the stream their forward ran on (autograd does that), so
+# the overlap carries over.  GLF_STREAMS=0 serialises everything on the current stream.
+STREAMS = os.environ.get("GLF_STREAMS", "1") != "0"
+N_SIDE_STREAMS = 12
+_side = {}
+
+
+def _walk_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _walk_tensors(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _walk_tensors(v)
+
+
+def parallel_sections(fns):
+    """Run the callables as independent sections, section i on side stream i, and join them on the current
+    stream.  Returns their results in order."""
+    if not STREAMS or len(fns) <= 1 or not torch.cuda.is_available():
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    dev = cur.device
+    pool = _side.setdefault(dev, [[], 0, 0])          # streams, next index, nesting depth
+    if not pool[0]:
+        pool[0] = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE_STREAMS)]
+    # Streams are handed out in call order, restarting with every top-level call: nested calls get streams of their
+    # own and a given section lands on the SAME stream every step (the caching allocator keeps one pool per stream;
+    # a wandering assignment would re-allocate every activation).  A stream shared by two sections only adds an
+    # ordering between them.
+    if pool[2] == 0:
+        pool[1] = 0
+    pool[2] += 1
+    used = []
+    for _ in fns:
+        st = pool[0][pool[1] % N_SIDE_STREAMS]
+        pool[1] += 1
+        if st.cuda_stream == cur.cuda_stream:
+            st = pool[0][pool[1] % N_SIDE_STREAMS]
+            pool[1] += 1
+        used.append(st)
+    outs = []
+    try:
+        for s, f in zip(used, fns):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs.append(f())
+    finally:
+        pool[2] -= 1
+    for s, out in zip(used, outs):
+        cur.wait_stream(s)
+        for t in _walk_tensors(out):
+            if t.is_cuda:
+                t.record_stream(cur)       # allocated on s, consumed on cur: keep the allocator from reusing it early
+    return outs
 
 
 # ----------------------------------------------------------------------------------------
