@@ -757,6 +757,10 @@ def fan_out(x: torch.Tensor, k: int):
 # the overlap carries over.  GLF_STREAMS=0 serialises everything on the current stream.
 STREAMS = os.environ.get("GLF_STREAMS", "1") != "0"
 N_SIDE_STREAMS = 12
+if STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # parameters' AccumulateGrad nodes live on the stream that first touched them (the default one when a gradient
+    # hook keeps them alive); gradients produced on a side stream are synchronised into it, which is intended
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 _side = {}
 
 
