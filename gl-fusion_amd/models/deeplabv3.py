@@ -71,12 +71,15 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(Conv2d(len(self.convs) * out_channels, out_channels, 1, bias=False),
                                      BatchNorm2d(out_channels), ReLU(), Dropout(0.5))
 
-    def forward_nhwc(self, x):
+    def trunk_nhwc(self, x):
+        """Everything up to (not including) the Dropout: branches, projection, BN, ReLU."""
         xs = ops.fan_out(x, len(self.convs))              # one-pass gradient fan-in over the five branches
         branches = [conv.forward_nhwc(xi) for conv, xi in zip(self.convs, xs)]
         y = ops.conv1x1_cat(self.project[0].weight, branches)
-        y = self.project[1].forward_nhwc(y, relu=True)
-        return self.project[3].forward_nhwc(y)
+        return self.project[1].forward_nhwc(y, relu=True)
+
+    def forward_nhwc(self, x):
+        return self.project[3].forward_nhwc(self.trunk_nhwc(x))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
@@ -90,10 +93,38 @@ class DeepLabHead(nn.Sequential):
                          ReLU(),
                          Conv2d(256, num_classes, 1))
 
-    def forward_nhwc(self, x):
-        y = self[0].forward_nhwc(x)
+    def _tail_nhwc(self, trunk):
+        y = self[0].project[3].forward_nhwc(trunk)        # Dropout: a fresh mask per call
         y = conv_bn_act(y, self[1], self[2], relu=True)
         return self[4].forward_nhwc(y)
+
+    def forward_nhwc(self, x):
+        return self._tail_nhwc(self[0].trunk_nhwc(x))
+
+    def forward_nhwc_shared(self, x):
+        """forward_nhwc(x) plus a token with which a LATER forward over the SAME input can be evaluated without
+        recomputing the ASPP trunk (Global_and_Local applies a view's classifier to f4 twice, ours.py:1806 and
+        1840): everything before the Dropout is a deterministic function of (input, weights) -- in train() the
+        BatchNorm layers normalise with the batch statistics of that same input -- so the second call shares the
+        trunk activation (its gradient becomes the sum of both uses) and differs only in what comes after:
+        its own Dropout mask, tail conv / BN / output conv, and one more running-statistics update of the trunk's
+        BatchNorm layers, which is replayed from the recorded batch statistics at the time of the second call."""
+        prev, ops.BN_TAP = ops.BN_TAP, []
+        try:
+            trunk = self[0].trunk_nhwc(x)
+            records = ops.BN_TAP
+        finally:
+            ops.BN_TAP = prev
+        t1, t2 = ops.fan_out(trunk, 2)
+        out = self._tail_nhwc(t1)
+        return out, (t2, records, out)
+
+    def forward_nhwc_replay(self, token):
+        trunk, records, first_out = token
+        if not self.training:
+            return first_out                              # eval(): no Dropout, frozen statistics -- the same tensor
+        ops.replay_bn_updates(records)
+        return self._tail_nhwc(trunk)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))

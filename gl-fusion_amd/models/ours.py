@@ -116,13 +116,13 @@ class Global_and_Local(nn.Module):
         # per view: encoder, then M_cls, M_ctr and the gated local features (ours.py:1795-1816)
         def view_section(v):
             f = self._encode_view(v, x[v])
-            fa, fb, fc, fg, fe = ops.fan_out(f, 5)          # classifier / centerness / gate / global fusion / mask_bb
-            cls = self.classifier[v].forward_nhwc(fa)
+            fa, fb, fc, fg = ops.fan_out(f, 4)              # classifier / centerness / gate / global fusion
+            cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
             ctr = self.centerness[v].forward_nhwc(fb)
-            return fe, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+            return again, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
 
         secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
-        f4 = {v: s[0] for v, s in zip(views, secs)}
+        cls_again = {v: s[0] for v, s in zip(views, secs)}
         f4_glob = {v: s[1] for v, s in zip(views, secs)}
         f4_local = {v: s[2] for v, s in zip(views, secs)}
         # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
@@ -133,7 +133,7 @@ class Global_and_Local(nn.Module):
 
         def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second
             m = ops.bilinear_up(self.classifier[v].forward_nhwc(fused[i]), ho, wo)              # ours.py:1837-1838
-            mb = ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), ho, wo)                # ours.py:1840-1841
+            mb = ops.bilinear_up(self.classifier[v].forward_nhwc_replay(cls_again[v]), ho, wo)  # ours.py:1840-1841, on f4[v]
             return m, mb
 
         heads = ops.parallel_sections([lambda i=i, v=v: head_section(i, v) for i, v in enumerate(views)])

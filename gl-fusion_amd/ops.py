@@ -515,6 +515,9 @@ def stem7x7(x, weight, bias, pad: int):
 # ----------------------------------------------------------------------------------------
 # BatchNorm (+ residual, + ReLU)
 # ----------------------------------------------------------------------------------------
+_last_bn = [None]          # (mean, invstd, rows) of the most recent BatchNormActFn.forward (read by BN_TAP)
+
+
 class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool,
@@ -542,6 +545,7 @@ class BatchNormActFn(Function):
         set_amax(y, am)
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.cfg = (rows, c, relu, training, residual is not None)
+        _last_bn[0] = (mean, invstd, rows)
         return y
 
     @staticmethod
@@ -562,6 +566,25 @@ class BatchNormActFn(Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+# When a list, every train-mode batch_norm_act call appends (module, batch mean, batch invstd, rows): enough to
+# replay the running-statistics update of a layer whose output is being reused instead of recomputed.
+BN_TAP = None
+
+
+def replay_bn_updates(records) -> None:
+    """Apply again the running-stat updates recorded by BN_TAP (same batch statistics): what a second forward of the
+    same modules over the same input would have done to running_mean / running_var / num_batches_tracked."""
+    with torch.no_grad():
+        for bn, mean, invstd, rows in records:
+            if not bn.track_running_stats or bn.running_mean is None:
+                continue
+            m = float(bn.momentum)
+            var = (invstd.double().pow(-2) - float(bn.eps)).clamp_(min=0.0) * (rows / max(rows - 1, 1))
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var.float(), alpha=m)
+            bn.num_batches_tracked.add_(1)
+
+
 def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None):
     """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
     optionally fused with a residual add and ReLU."""
@@ -573,11 +596,14 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
     if bn.momentum is None and training and bn.track_running_stats:
         raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")
     track = training and bn.track_running_stats
-    return BatchNormActFn.apply(x, bn.weight, bn.bias, residual,
-                                bn.running_mean if (track or not training) else None,
-                                bn.running_var if (track or not training) else None,
-                                bn.num_batches_tracked if track else None,
-                                training, momentum, float(bn.eps), relu)
+    y = BatchNormActFn.apply(x, bn.weight, bn.bias, residual,
+                             bn.running_mean if (track or not training) else None,
+                             bn.running_var if (track or not training) else None,
+                             bn.num_batches_tracked if track else None,
+                             training, momentum, float(bn.eps), relu)
+    if BN_TAP is not None and track:
+        BN_TAP.append((bn,) + _last_bn[0])
+    return y
 
 
 # ----------------------------------------------------------------------------------------
