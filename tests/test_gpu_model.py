@@ -273,3 +273,36 @@ def test_error_behaviour_matches_torch():
         head(x)
     head.eval()
     assert tuple(head(x).shape) == (1, 5, 28, 28)
+
+
+def test_shared_trunk_keeps_reference_running_stats():
+    """Global_and_Local applies classifier[v] three times per forward (f4, fused, f4 again).  The engine shares the ASPP
+    trunk between the two f4 calls and replays the BatchNorm running-statistics update instead of recomputing; the
+    buffers after one train() forward must equal the oracle's, which really evaluates all three calls."""
+    from glfusion_amd.models import Global_and_Local
+    views, n = ["1"], 4
+    ref = orc.Global_and_Local(views)
+    orc.closed_form_fill(ref, salt=3)
+    orc.set_dropout(ref, 0.0)
+    model = Global_and_Local(views)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    orc.set_dropout(model, 0.0)
+    model = model.to(DEV).train()
+    ref.train()
+    imgs = orc.closed_form_images(views, n, 112, 112)
+    with torch.no_grad():
+        ref(imgs)
+        model({v: t.to(DEV) for v, t in imgs.items()})
+    want = dict(ref.named_buffers())
+    checked = 0
+    for name, buf in model.named_buffers():
+        if not name.startswith("classifier.") and not name.startswith("centerness."):
+            continue
+        if name.endswith("num_batches_tracked"):
+            assert int(buf) == int(want[name]), name
+            if name.startswith("classifier.1.0."):
+                assert int(buf) == 3, name                 # three updates of every trunk layer, one of them replayed
+        else:
+            assert close(buf, want[name], 1e-5), name
+        checked += 1
+    assert checked >= 3 * 14
