@@ -35,7 +35,7 @@ class GemmParams(C.Structure):
 
 
 _SCALARS = {
-    "int": C.c_int, "float": C.c_float, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+    "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
     "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None,
 }
 

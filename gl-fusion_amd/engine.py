@@ -15,6 +15,7 @@ import torch
 
 from . import ops
 from .ddp import GradAllReducer, all_reduce_counts
+from .optim import Adam
 from .models import Global_and_Local
 
 
@@ -50,8 +51,9 @@ class Trainer:
         self.print_val = tr.get("global_rank", 0) == 0                       # main.py:92
         self.model = Global_and_Local(view_num=self.view_num).to(self.device)  # main.py:150
         opt = config["net"]["opt"]
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=opt["lr"], betas=opt["params"],
-                                          weight_decay=opt["weight_decay"])    # main.py:162-165
+        if opt.get("opt_name", "Adam") != "Adam":
+            raise NotImplementedError("glfusion_amd: only the Adam branch of main.py:158-165 is built (the shipped config)")
+        self.optimizer = Adam(self.model.parameters(), lr=opt["lr"], weight_decay=opt["weight_decay"])    # main.py:162-165, fused
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=tr["num_epochs"])   # main.py:168
         self.reducer = GradAllReducer(self.model)
         self.reducer.broadcast_parameters(0)

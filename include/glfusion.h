@@ -243,6 +243,18 @@ int glf_overlap_counts(const float* logits, const float* target, int64_t* counts
 /* bias gradient: db[c] = sum_r dy[r][c]; workspace glf_bn_workspace(rows, c) doubles. */
 int glf_colsum(const float* dy, int lddy, float* db, int rows, int c, double* workspace, glf_stream_t s);
 
+/* ---------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam as main.py:162-165 builds it (L2 weight decay folded into the
+ * gradient, no amsgrad), every parameter of one step count in ONE launch.  `table` is a DEVICE array of
+ * n_rows x 5 int64 { param ptr, grad ptr, exp_avg ptr, exp_avg_sq ptr, n elements }, one row per chunk of a
+ * parameter; `step` = the parameters' step count t, counted from 1 (torch keeps one per parameter; parameters
+ * with different counts go into separate calls).  The bias corrections, 1 - beta and lr / (1 - beta1^t) are
+ * formed in double on the host as torch does.
+ * Updates param, exp_avg and exp_avg_sq in place with the operation order of torch.optim._functional.adam.
+ * ------------------------------------------------------------------------------------- */
+int glf_adam_step(const int64_t* table, int n_rows, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int64_t step, glf_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,3 +76,13 @@ def test_tap_masks():
     assert tap_mask(2, 28, 28, 28, 28, 3, 3, 1, 36, 36) == 1 << 4
     assert tap_mask(1, 28, 28, 55, 55, 3, 3, 2, 1, 1) == full
     assert tap_mask(2, 55, 55, 28, 28, 3, 3, 2, 1, 1) == full
+
+
+def test_adam_pointer_table_chunks():
+    """Host logic of the fused optimizer: parameters are cut into rows of at most CHUNK elements, pointers advanced."""
+    import numpy as np
+    from glfusion_amd import optim
+    rows = optim._chunk_rows([(1000, 2000, 3000, 4000, optim.CHUNK + 7), (16, 32, 48, 64, 5)])
+    assert rows.tolist() == [[1000, 2000, 3000, 4000, optim.CHUNK],
+                             [1000 + 4 * optim.CHUNK, 2000 + 4 * optim.CHUNK, 3000 + 4 * optim.CHUNK, 4000 + 4 * optim.CHUNK, 7],
+                             [16, 32, 48, 64, 5]]
