@@ -3,8 +3,9 @@
 `_calculate_overlap_metrics`, `save()`.  The reference's data layer needs NIfTI files that are not
 shipped (absolute paths on the authors' machine), so loaders here produce synthetic clips with
 the reference's tensor contract: images [N,1,112,112] in [0,1], masks [N,5,112,112] in {0,1}
-(datasets/loader.py:298-330).  The temporal cycle loss (main.py:650-798) is SURVEY row f1 (next), so
-`is_cycle=True` is accepted and ignored with a notice.
+(datasets/loader.py:298-330); the unlabelled "video" loader of the cycle term yields clips of `clip_length`
+frames per view (main.py:213-218).  `is_cycle=True` adds the temporal cycle-consistency loss of main.py:213-237
+(second forward on the video clip, pooled global-fusion features, seg_cycle / dense_seg_cycle, total = seg + 1e-2 cyc).
 """
 from __future__ import annotations
 
@@ -60,14 +61,34 @@ class Trainer:
         frames = tr["batch_size"] * tr.get("frames_per_clip", 1)
         self.loader = SyntheticClips(self.view_num, frames, 112, 112, self.device, seed=1234 + tr.get("global_rank", 0),
                                      length=tr.get("iters_per_epoch", 4))
+        self.dense_cyc = bool(tr.get("dense_cyc", False))                      # main.py:228
+        self.video_loader = SyntheticClips(self.view_num, int(tr.get("clip_length", 40)), 112, 112, self.device,
+                                           seed=4321 + tr.get("global_rank", 0), length=tr.get("iters_per_epoch", 4))
 
-    def train_step(self, imgs, masks) -> torch.Tensor:
-        """main.py:202-243 without the cycle term: forward, sum_v BCE-sum, backward, Adam step."""
+    def cycle_loss(self, video: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """main.py:213-235: second forward on an unlabelled clip [T,1,H,W] per view, global-fusion features summed
+        over (h, w), seg_cycle (or dense_seg_cycle) per view with target_region 16, cyc_off 2, chunk_size 3,
+        temperature 10."""
+        _, _, feat_out, _ = self.model(video)
+        feats = ops.pooled_fusion_features(feat_out)
+        total = None
+        for view in self.view_num:
+            if self.dense_cyc:
+                l = ops.dense_seg_cycle(feats[view], 16, 2, 3, 10, soft_label=False, is_overlap=True)
+            else:
+                l = ops.seg_cycle(feats[view], 16, 2, 3, 10)
+            total = l if total is None else total + l
+        return total
+
+    def train_step(self, imgs, masks, video=None) -> torch.Tensor:
+        """main.py:202-243: forward, sum_v BCE-sum (+ 1e-2 x cycle loss on `video`), backward, Adam step."""
         pred_frames, _, _, _ = self.model(imgs)
         loss = None
         for view in self.test_view:
             l = ops.bce_with_logits_sum(pred_frames[view], masks[view])
             loss = l if loss is None else loss + l
+        if video is not None:
+            loss = loss + 1e-2 * self.cycle_loss(video)                        # main.py:237
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.reducer.finalize()
@@ -75,12 +96,11 @@ class Trainer:
         return loss.detach(), pred_frames
 
     def train(self, is_backbone: bool = False, is_cycle: bool = True):
-        if is_cycle and self.print_val:
-            print("[glfusion_amd] temporal cycle loss (main.py:650-798) is not on the built path yet: training on seg_loss only")
         for epoch in range(self.config["train"]["num_epochs"]):
             self.model.train()
             for imgs, masks in self.loader:
-                loss, pred = self.train_step(imgs, masks)
+                video = self.video_loader.batch()[0] if is_cycle else None
+                loss, pred = self.train_step(imgs, masks, video)
             self.scheduler.step()
             if self.print_val:
                 dice = {v: self._calculate_overlap_metrics(masks[v], pred[v].detach())[1] for v in self.test_view}

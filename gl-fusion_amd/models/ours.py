@@ -141,5 +141,7 @@ class Global_and_Local(nn.Module):
         for i, v in enumerate(views):
             f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)       # == global_conv_feat[:, :, i, :, :]
             f4_l[v] = l_out[:, i].permute(0, 3, 1, 2)
+            f4_g[v]._glf_stack = (g_out, i)                 # lets ops.pooled_fusion_features pool the block once
+            f4_l[v]._glf_stack = (l_out, i)
             mask[v], mask_bb[v] = heads[i]
         return mask, mask_bb, f4_g, f4_l

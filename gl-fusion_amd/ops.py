@@ -1024,6 +1024,94 @@ def overlap_metrics_from_counts(counts: torch.Tensor, eps: float = 1e-5):
 
 
 # ----------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------
+# temporal cycle-consistency loss (main.py:213-235, 650-798)
+# ----------------------------------------------------------------------------------------
+class SumHWFn(Function):
+    """x [..., h, w, C] channels-last (any number of leading frame dims) -> sum over (h, w): [..., C].
+    `f4_global_fusion[v].sum(dim=(2, 3))` of main.py:226."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk(x, "sum_hw input"))
+        *lead, h, w, c = x.shape
+        n = 1
+        for d in lead:
+            n *= d
+        y = torch.empty(*lead, c, dtype=torch.float32, device=x.device)
+        check(lib.glf_sum_rows_fwd(_p(x), c, _p(y), 1.0, n, h * w, c, _stream()), "sum_hw")
+        ctx.cfg = (tuple(x.shape), n, h * w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        shape, n, p, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        check(lib.glf_bcast_rows_scaled(_p(dy), _p(dx), c, 1.0, n, p, c, _stream()), "sum_hw_bwd")
+        return dx
+
+
+def sum_hw(x: torch.Tensor) -> torch.Tensor:
+    return SumHWFn.apply(x)
+
+
+def pooled_fusion_features(f4_fusion: dict) -> dict:
+    """{view: [T, C]} = f4_fusion[view].sum(dim=(2, 3)) (main.py:226) for the dict Global_and_Local.forward returns.
+    Its entries are per-view slices of ONE [T, V, h, w, C] block (the fusion module's output): the block is pooled
+    once (one read, and one broadcast in backward) instead of V strided reductions through sliced views."""
+    views = list(f4_fusion)
+    base = getattr(f4_fusion[views[0]], "_glf_stack", None)
+    if base is not None and all(getattr(f4_fusion[v], "_glf_stack", (None, -1))[0] is base[0] for v in views):
+        pooled = sum_hw(base[0])                                   # [T, V, C]
+        return {v: pooled[:, f4_fusion[v]._glf_stack[1]] for v in views}
+    return {v: sum_hw(to_nhwc(f4_fusion[v])) for v in views}
+
+
+class SegCycleFn(Function):
+    @staticmethod
+    def forward(ctx, feat, target_region: int, cyc_off: int, chunk_size: int, temperature: float, start0: int, n_starts: int,
+                stride: int, weight: float, soft: bool):
+        feat = _contig(_chk(feat, "cycle features"))
+        if feat.dim() != 2:
+            raise RuntimeError("seg_cycle: features must be [T, F]")
+        t, f = feat.shape
+        loss = torch.empty((), dtype=torch.float32, device=feat.device)
+        dfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        check(lib.glf_seg_cycle(_p(feat), t, f, target_region, cyc_off, chunk_size, float(temperature), start0, n_starts, stride,
+                                float(weight), int(soft), _p(loss), _p(dfeat), _stream()), "seg_cycle")
+        ctx.save_for_backward(dfeat)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        (dfeat,) = ctx.saved_tensors
+        out = torch.empty_like(dfeat)
+        check(lib.glf_scale(_p(dfeat), _p(out), dfeat.numel(), 1.0, _p(_contig(dloss)), _stream()), "seg_cycle_bwd")
+        return out, None, None, None, None, None, None, None, None, None
+
+
+def seg_cycle(feat, target_region: int = 16, cyc_off: int = 2, chunk_size: int = 3, temperature: float = 10, start: int = None):
+    """Trainer.seg_cycle (main.py:650-718).  `start` is the query start frame the reference draws with
+    np.random.choice(target_region - (chunk_size + cyc_off) + 1) (main.py:655); None draws it the same way."""
+    n = target_region - (chunk_size + cyc_off) + 1
+    if start is None:
+        import numpy as np
+        start = int(np.random.choice(n))
+    return SegCycleFn.apply(feat, target_region, cyc_off, chunk_size, temperature, int(start), 1, 1, 1.0, False)
+
+
+def dense_seg_cycle(feat, target_region: int = 16, cyc_off: int = 2, chunk_size: int = 3, temperature: float = 10,
+                    soft_label: bool = False, is_overlap: bool = True):
+    """Trainer.dense_seg_cycle (main.py:720-798): every start frame, averaged over the number of possible starts."""
+    n = target_region - (chunk_size + cyc_off) + 1
+    stride = 1 if is_overlap else chunk_size
+    return SegCycleFn.apply(feat, target_region, cyc_off, chunk_size, temperature, 0, (n + stride - 1) // stride, stride, 1.0 / n,
+                            bool(soft_label))
+
+
 # contraction precision (process-wide): "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
 # "f16x3" = scaled split-fp16 (3 MFMAs per product)
 PRECISIONS = ("f32", "bf16x6", "f16x3")

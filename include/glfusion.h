@@ -255,6 +255,22 @@ int glf_colsum(const float* dy, int lddy, float* db, int rows, int c, double* wo
 int glf_adam_step(const int64_t* table, int n_rows, double lr, double beta1, double beta2, double eps,
                   double weight_decay, int64_t step, glf_stream_t s);
 
+/* ---------------------------------------------------------------------------------------
+ * Temporal cycle-consistency loss: Trainer.seg_cycle and Trainer.dense_seg_cycle
+ * (main.py:650-718, 720-798) on the pooled fusion features feat [T][F] (main.py:226-231: T = 40,
+ * target_region 16, cyc_off 2, chunk_size 3, temperature 10).  *loss_out = weight * sum over the start frames
+ * start0, start0 + stride, ... (n_starts of them) of the mean BCE-with-logits; dfeat [T][F] (may be NULL)
+ * receives d loss / d feat.  seg_cycle: n_starts = 1, weight = 1, start0 = the frame the reference draws with
+ * np.random.choice (an explicit input here).  dense_seg_cycle: start0 = 0, stride = 1 (is_overlap) or
+ * chunk_size, weight = 1 / (target_region - chunk_size - cyc_off + 1); soft_label as main.py:790-791.
+ * ------------------------------------------------------------------------------------- */
+int glf_seg_cycle(const float* feat, int T, int F, int target_region, int cyc_off, int chunk_size, float temperature,
+                  int start0, int n_starts, int stride, float weight, int soft_label, float* loss_out, float* dfeat,
+                  glf_stream_t s);
+/* y = x * scale * (*scale_dev) (scale_dev: device scalar, may be NULL): a saved gradient times autograd's
+ * upstream gradient. */
+int glf_scale(const float* x, float* y, int64_t numel, float scale, const float* scale_dev, glf_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -400,6 +400,61 @@ def closed_form_targets(views: Sequence[str], n: int, c: int = 5, h: int = 112, 
             for i, v in enumerate(views)}
 
 
+# ------------------------------------------------------------------------------------------------
+# temporal cycle-consistency loss: Trainer.seg_cycle / dense_seg_cycle, main.py:650-798
+# ------------------------------------------------------------------------------------------------
+def _cycle_logits(feat: torch.Tensor, target_region: int, cyc_off: int, chunk_size: int, temperature: float, start: int):
+    """The logits `q_similarity_averaged` of main.py:650-711 for one start frame, in index form.
+
+    feat [T, F]: frames [0, R) are queries, [R, T) keys (main.py:651-653).  A chunk of `chunk_size` consecutive query
+    frames starting at `start` is matched against every chunk of consecutive key frames (squared distance summed
+    over the chunk, main.py:665-676), the matches are soft-maxed (main.py:678-679) into one weighted key chunk
+    (main.py:684-691), which is then matched back against the chunks of query frames [cyc_off, R) (main.py:695-709)."""
+    R, c, off = target_region, chunk_size, cyc_off
+    T, F = feat.shape
+    kn = T - R
+    q_all, q_cyc, key = feat[:R], feat[off:R], feat[R:]
+    query = q_all[start:start + c]                                            # main.py:659
+    j = torch.arange(c)
+    n_beta = kn - (c + off) + 1
+    d = ((key[:, None, :] - query[None, :, :]) ** 2).sum(-1)                  # [kn, c]   main.py:665-667
+    rows = (torch.arange(n_beta)[:, None] + j[None, :]) % kn                  # main.py:670-674 (first n_beta rows)
+    sim = -d[rows, j[None, :]].sum(1)                                         # main.py:675-676
+    beta = torch.softmax(sim / F / c * temperature, dim=0)                    # main.py:678-679
+    rows_b = (torch.arange(off, kn - c + 1)[:, None] + j[None, :]) % kn       # main.py:684-688: chunks off .. kn-c
+    weighted = (beta[:, None, None] * key[rows_b]).sum(0)                     # [c, F]   main.py:690-691
+    rc = R - off
+    n_out = rc - c + 1
+    qd = ((q_cyc[:, None, :] - weighted[None, :, :]) ** 2).sum(-1)            # [rc, c]  main.py:695-697
+    rows_q = (torch.arange(n_out)[:, None] + j[None, :]) % rc                 # main.py:699-703
+    return -qd[rows_q, j[None, :]].sum(1) / F / c * temperature              # main.py:706-709
+
+
+def seg_cycle(feat: torch.Tensor, target_region: int = 16, cyc_off: int = 2, chunk_size: int = 3, temperature: float = 10,
+              start: int = 0) -> torch.Tensor:
+    """main.py:650-718 with the random start frame (np.random.choice, main.py:655) as an explicit argument."""
+    z = _cycle_logits(feat, target_region, cyc_off, chunk_size, temperature, start)
+    target = torch.zeros_like(z)
+    target[start] = 1.0                                                       # main.py:656
+    return F.binary_cross_entropy_with_logits(z, target)                      # main.py:716 (mean)
+
+
+def dense_seg_cycle(feat: torch.Tensor, target_region: int = 16, cyc_off: int = 2, chunk_size: int = 3, temperature: float = 10,
+                    soft_label: bool = False, is_overlap: bool = True) -> torch.Tensor:
+    """main.py:720-798: every start frame (stride chunk_size when not overlapping); the sum is divided by the number
+    of POSSIBLE starts whatever the stride (main.py:798)."""
+    n = target_region - (chunk_size + cyc_off) + 1
+    total = 0
+    for start in range(0, n, 1 if is_overlap else chunk_size):                # main.py:730
+        z = _cycle_logits(feat, target_region, cyc_off, chunk_size, temperature, start)
+        target = torch.zeros_like(z)
+        target[start] = 1.0
+        if soft_label:                                                        # main.py:790-791
+            target = torch.where(target == 1, torch.full_like(z, 0.8), torch.full_like(z, 0.2 / (n - 1)))
+        total = total + F.binary_cross_entropy_with_logits(z, target)
+    return total / n
+
+
 def set_dropout(module: nn.Module, p: float) -> None:
     for m in module.modules():
         if isinstance(m, nn.Dropout):

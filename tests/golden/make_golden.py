@@ -74,7 +74,7 @@ def grads_summary(model: torch.nn.Module):
 
 
 def main() -> None:
-    only = set(sys.argv[1:])          # optional: tpavi head eval train
+    only = set(sys.argv[1:])          # optional: tpavi head eval train cycle
     want = lambda name: not only or name in only
     torch.manual_seed(0)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -202,5 +202,52 @@ def main() -> None:
     print("train loss", float(loss))
 
 
+def reference_cycle_functions():
+    """Trainer.seg_cycle / Trainer.dense_seg_cycle (main.py:650-798) as callables.  main.py cannot be imported (it
+    needs utils.PCGrad and the authors' data files), so the two method definitions are cut out of its syntax tree
+    and compiled on their own -- the reference's code, executed verbatim, nothing of it is written to disk.
+    `np.random.choice` (the random start frame, main.py:655) is replaced by a stub that returns `forced_start`."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "main.py")).read())
+    fns = [n for cls in tree.body if isinstance(cls, ast.ClassDef) and cls.name == "Trainer"
+           for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("seg_cycle", "dense_seg_cycle")]
+    assert len(fns) == 2
+    mod = ast.Module(body=fns, type_ignores=[])
+    state = {"start": 0}
+    fake_np = types.SimpleNamespace(random=types.SimpleNamespace(choice=lambda n: state["start"]))
+    ns = {"torch": torch, "np": fake_np}
+    exec(compile(mod, "<reference main.py:650-798>", "exec"), ns)
+    return ns["seg_cycle"], ns["dense_seg_cycle"], state
+
+
+def cycle_fixture() -> None:
+    seg_cycle, dense_seg_cycle, state = reference_cycle_functions()
+    me = types.SimpleNamespace(device=torch.device("cpu"))
+    d = {}
+    # the call of main.py:227-231: T = 40 frames, target_region 16, cyc_off 2, chunk_size 3, temperature 10
+    for tag, (T, F, scale) in {"full": (40, 2048, 30.0), "small": (40, 64, 3.0), "short": (29, 40, 2.0)}.items():
+        feat0 = orc.closed_form_tensor((T, F), 700 + F, 0.0, scale)
+        d[f"{tag}:cfg"] = np.array([T, F, scale, 700 + F], dtype=np.float64)
+        for start in (0, 5, 11):
+            state["start"] = start
+            feat = feat0.clone().requires_grad_(True)
+            loss = seg_cycle(me, feat, target_region=16, cyc_off=2, chunk_size=3, temperature=10)
+            loss.backward()
+            d[f"{tag}:seg:{start}:loss"] = t2n(loss)
+            d[f"{tag}:seg:{start}:dfeat"] = t2n(feat.grad)
+        for soft, overlap in ((False, True), (True, True), (False, False)):
+            feat = feat0.clone().requires_grad_(True)
+            loss = dense_seg_cycle(me, feat, target_region=16, cyc_off=2, chunk_size=3, temperature=10,
+                                   soft_label=soft, is_overlap=overlap)
+            loss.backward()
+            d[f"{tag}:dense:{int(soft)}{int(overlap)}:loss"] = t2n(loss)
+            d[f"{tag}:dense:{int(soft)}{int(overlap)}:dfeat"] = t2n(feat.grad)
+    np.savez_compressed(os.path.join(HERE, "seg_cycle.npz"), **d)
+    print("cycle fixture:", {k: float(v) for k, v in d.items() if k.endswith("loss")})
+
+
 if __name__ == "__main__":
-    main()
+    if not sys.argv[1:] or "cycle" in sys.argv[1:]:
+        cycle_fixture()
+    if sys.argv[1:] != ["cycle"]:
+        main()

@@ -1,0 +1,100 @@
+"""Caller-side rows f1 / f2 end to end: the reference's inner training step (main.py:202-243) with the cycle term and
+the Adam update, HIP engine vs the oracle on the CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import glfusion_ref as orc   # the checker (tests only)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_training_step_with_cycle_loss_and_adam_vs_oracle():
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    from glfusion_amd.optim import Adam
+    views, n, t_video, start, temp = ["1"], 4, 29, 5, 0.02
+    ref = orc.Global_and_Local(views)
+    orc.closed_form_fill(ref, salt=5)
+    orc.set_dropout(ref, 0.0)
+    model = Global_and_Local(views)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    orc.set_dropout(model, 0.0)
+    model = model.to(DEV).train()
+    ref.train()
+    imgs = orc.closed_form_images(views, n, 112, 112)
+    tgts = orc.closed_form_targets(views, n)
+    video = {v: orc.closed_form_tensor((t_video, 1, 112, 112), 77, 0.0, 1.0) for v in views}
+    # (the closed-form weights give pooled features of ~1e3; with the shipped temperature 10 the chunk soft-max is
+    # saturated and the loss's own fp32 conditioning, measured against fp64, is 1e-4 for BOTH sides -- the kernel is
+    # pinned on that regime in test_gpu_cycle.py; here the temperature keeps the plumbing test well-conditioned)
+
+    # oracle: main.py:207-241 (seg + 1e-2 * cyc), then torch.optim.Adam (main.py:162-165)
+    params_ref = [p for nm, p in ref.named_parameters() if not nm.startswith("network.")]
+    opt_ref = torch.optim.Adam(params_ref, lr=3e-4, weight_decay=1e-5)
+    pred = ref(imgs)[0]
+    seg = sum(torch.nn.functional.binary_cross_entropy_with_logits(pred[v], tgts[v], reduction="sum") for v in views)
+    feat = ref(video)[2]
+    cyc = sum(orc.seg_cycle(feat[v].sum(dim=(2, 3)), 16, 2, 3, temp, start) for v in views)
+    total_ref = seg + 1e-2 * cyc
+    opt_ref.zero_grad()
+    total_ref.backward()
+    gref = {nm: p.grad.clone() for nm, p in ref.named_parameters() if p.grad is not None}
+    opt_ref.step()
+
+    # engine
+    opt = Adam([p for nm, p in model.named_parameters() if not nm.startswith("network.")], lr=3e-4, weight_decay=1e-5)
+    pred = model({v: t.to(DEV) for v, t in imgs.items()})[0]
+    seg = sum(ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
+    feats = ops.pooled_fusion_features(model({v: t.to(DEV) for v, t in video.items()})[2])
+    cyc_e = sum(ops.seg_cycle(feats[v], 16, 2, 3, temp, start) for v in views)
+    total = seg + 1e-2 * cyc_e
+    opt.zero_grad()
+    total.backward()
+
+    assert abs(float(cyc_e) - float(cyc)) <= 1e-3 * abs(float(cyc)) + 1e-6          # through a 53-layer fp32 network
+    assert abs(float(total) - float(total_ref)) <= 2e-5 * abs(float(total_ref))
+    # gradients that the cycle term reaches only through the global fusion block
+    top = max(float(w.norm()) for nm, w in gref.items() if nm.startswith("global_attn."))
+    for nm, p in model.named_parameters():
+        if nm.startswith("global_attn.") and nm in gref and not nm.startswith("global_attn.align_channel"):
+            g, w = p.grad.double().cpu(), gref[nm].double()
+            # fp32 gradients of this network carry ~0.3-0.5 % of rounding noise between ANY two fp32 evaluations (the
+            # reference against its own fp64 run: tests/golden/e2e_train_step.npz, grad_norms vs grad_norms64), and
+            # parameters whose true gradient is zero (a bias in front of a train-mode BatchNorm) hold nothing else
+            assert float((g - w).norm()) <= 2e-2 * float(w.norm()) + 1e-3 * top, nm
+    opt.step()
+    # The first Adam step moves every element by lr * g / (|g| + eps) ~ lr * sign(g): elements whose gradient is
+    # pure rounding noise (true value 0) may legitimately move the other way, everything else must land together.
+    n_el, n_off, moved = 0, 0, 0
+    want = dict(ref.named_parameters())
+    for nm, p in model.named_parameters():
+        if nm.startswith("network.") or nm not in gref:
+            continue
+        a, b = p.detach().double().cpu(), want[nm].detach().double()
+        n_el += a.numel()
+        n_off += int(((a - b).abs() > 0.1 * 3e-4).sum())
+        moved += 1
+    assert moved > 100
+    assert n_off <= 0.01 * n_el, (n_off, n_el)
+
+
+def test_trainer_surface_runs_cycle_training_and_checkpoints(tmp_path):
+    from glfusion_amd.engine import Trainer
+    cfg = {"train": {"batch_size": 2, "num_epochs": 1, "clip_length": 29, "view_num": ["1"], "test_view": ["1"], "dense_cyc": True,
+                     "save_dir": str(tmp_path), "iters_per_epoch": 1, "global_rank": 0},
+           "net": {"opt": {"opt_name": "Adam", "lr": 3e-4, "params": (0.9, 0.999), "weight_decay": 1e-5}}}
+    t = Trainer(cfg)
+    before = t.model.classifier["1"][4].weight.detach().clone()
+    t.train(is_backbone=False, is_cycle=True)
+    assert not torch.equal(before, t.model.classifier["1"][4].weight)
+    ckpt = os.path.join(str(tmp_path), "net_00000.pth")
+    assert os.path.exists(ckpt) and open(os.path.join(str(tmp_path), "latest.ckpt")).read().strip() == "0"
+    sd = torch.load(ckpt, map_location="cpu")["network"]              # main.py:857-872 format
+    ref = orc.Global_and_Local(["1"])
+    ref.load_state_dict(sd, strict=True)                               # the oracle (== reference key set) accepts it
+    out = t.eval(net_path=ckpt)
+    assert set(out) == {"1"} and all(np.isfinite(x) for x in out["1"])

@@ -126,3 +126,28 @@ def test_e2e_train_step(golden_dir):
             flat = sd[k[3:]].reshape(-1).float()
             idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(9, flat.numel())).astype(np.int64))
             assert close(flat[torch.from_numpy(idx)], g[k], 1e-5), k
+
+
+def test_oracle_cycle_losses_match_reference_fixture(golden_dir):
+    """oracle.seg_cycle / dense_seg_cycle against vectors produced by the reference's own main.py:650-798."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(golden_dir, "seg_cycle.npz"))
+    for tag in ("full", "small", "short"):
+        T, F, scale, salt = g[f"{tag}:cfg"]
+        feat0 = orc.closed_form_tensor((int(T), int(F)), int(salt), 0.0, float(scale))
+        for start in (0, 5, 11):
+            f = feat0.clone().requires_grad_(True)
+            loss = orc.seg_cycle(f, 16, 2, 3, 10, start)
+            loss.backward()
+            assert abs(float(loss.detach()) - float(g[f"{tag}:seg:{start}:loss"])) <= 1e-6 * abs(float(g[f"{tag}:seg:{start}:loss"]))
+            ref = torch.from_numpy(g[f"{tag}:seg:{start}:dfeat"])
+            assert float((f.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        for soft, overlap in ((0, 1), (1, 1), (0, 0)):
+            f = feat0.clone().requires_grad_(True)
+            loss = orc.dense_seg_cycle(f, 16, 2, 3, 10, bool(soft), bool(overlap))
+            loss.backward()
+            key = f"{tag}:dense:{soft}{overlap}"
+            assert abs(float(loss.detach()) - float(g[key + ":loss"])) <= 1e-6 * abs(float(g[key + ":loss"]))
+            ref = torch.from_numpy(g[key + ":dfeat"])
+            assert float((f.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
