@@ -54,8 +54,10 @@ class TPAVIModule(nn.Module):
         return self.forward_nvhwc(x5).permute(0, 4, 1, 2, 3), 0
 
 
-class Global_and_Local(nn.Module):
-    """ours.py:1708-1843."""
+class _PerViewNetworks(nn.Module):
+    """The constructor the reference repeats in every multi-view variant (ours.py:1709-1744, 2000-2037, 2114-2149):
+    per view a copy of the stem, layer1-4, a 5-class `classifier` head and a 1-class `centerness` head, all cut out of
+    one `network` template (which stays registered, so its dead parameters are part of the state_dict)."""
 
     def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
         super().__init__()
@@ -83,8 +85,6 @@ class Global_and_Local(nn.Module):
             self.classifier[view][-1] = Conv2d(last.in_channels, 5, kernel_size=last.kernel_size)
             self.centerness[view] = copy.deepcopy(self.network.classifier)
             self.centerness[view][-1] = Conv2d(last.in_channels, 1, kernel_size=last.kernel_size)
-        self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
-        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
     # -- encoder (ours.py:1795-1800) -------------------------------------------------------
     def _encode_view(self, view: str, xv: torch.Tensor) -> torch.Tensor:
@@ -107,6 +107,16 @@ class Global_and_Local(nn.Module):
         f4 = self._encode(x)
         mask = {v: ops.bilinear_up(self.classifier[v].forward_nhwc(f4[v]), int(hw[0]), int(hw[1])) for v in self.view_num}
         return mask, {v: ops.from_nhwc(f) for v, f in f4.items()}
+
+
+
+class Global_and_Local(_PerViewNetworks):
+    """ours.py:1708-1843."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
+        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
     def forward(self, x: Dict[str, torch.Tensor]):
         views = list(self.view_num)
@@ -145,3 +155,80 @@ class Global_and_Local(nn.Module):
             f4_l[v]._glf_stack = (l_out, i)
             mask[v], mask_bb[v] = heads[i]
         return mask, mask_bb, f4_g, f4_l
+
+
+class Global_only(_PerViewNetworks):
+    """Ablation without the local branch (ours.py:1999-2111): mask = classifier(global fusion), mask_bb =
+    classifier(f4); the centerness heads exist (state_dict) but are not evaluated.  Returns
+    (mask, mask_bb, f4_global_fusion, None)."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        views = list(self.view_num)
+        hw = x[views[0]].shape[-2:]
+        ho, wo = int(hw[0]), int(hw[1])
+
+        def view_section(v):                                 # ours.py:2085-2090
+            return ops.fan_out(self._encode_view(v, x[v]), 2)             # global fusion / mask_bb
+
+        secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
+        g_out = self.global_attn.forward_nvhwc(ops.stack_views([s[0] for s in secs]))            # ours.py:2093-2097
+        per_view = ops.split_views(g_out)
+
+        def head_section(i, v):                               # ours.py:2103-2108: fused mask first, backbone mask second
+            m = ops.bilinear_up(self.classifier[v].forward_nhwc(per_view[i]), ho, wo)
+            mb = ops.bilinear_up(self.classifier[v].forward_nhwc(secs[i][1]), ho, wo)
+            return m, mb
+
+        heads = ops.parallel_sections([lambda i=i, v=v: head_section(i, v) for i, v in enumerate(views)])
+        mask, mask_bb, f4_g = {}, {}, {}
+        for i, v in enumerate(views):
+            f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)
+            f4_g[v]._glf_stack = (g_out, i)
+            mask[v], mask_bb[v] = heads[i]
+        return mask, mask_bb, f4_g, None
+
+
+class Local_only(_PerViewNetworks):
+    """Ablation without the global branch (ours.py:2113-2249): the centre-aware gate, local fusion only.  Returns
+    (mask, mask_bb, atten_map, f4_fusion) with atten_map[v] = sigmoid(w * max_c sigmoid(cls) * sigmoid(ctr)) [N,1,h,w]
+    (returned detached: nothing on the reference's path differentiates through the returned map) and
+    f4_fusion[v] the local-fusion features."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        views = list(self.view_num)
+        hw = x[views[0]].shape[-2:]
+        ho, wo = int(hw[0]), int(hw[1])
+
+        def view_section(v):                                  # ours.py:2202-2223
+            f = self._encode_view(v, x[v])
+            fa, fb, fc = ops.fan_out(f, 3)                    # classifier / centerness / gate
+            cls, again = self.classifier[v].forward_nhwc_shared(fa)       # `again`: the mask_bb call on the same f4
+            ctr = self.centerness[v].forward_nhwc(fb)
+            gated, amap = ops.local_gate_with_map(cls, ctr, fc, self.center_aware_weight)
+            return again, gated, amap
+
+        secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
+        l_out = self.local_attn.forward_nvhwc(ops.stack_views([s[1] for s in secs]))             # ours.py:2226-2231
+        per_view = ops.split_views(l_out)
+
+        def head_section(i, v):                               # ours.py:2242-2247
+            m = ops.bilinear_up(self.classifier[v].forward_nhwc(per_view[i]), ho, wo)
+            mb = ops.bilinear_up(self.classifier[v].forward_nhwc_replay(secs[i][0]), ho, wo)
+            return m, mb
+
+        heads = ops.parallel_sections([lambda i=i, v=v: head_section(i, v) for i, v in enumerate(views)])
+        mask, mask_bb, atten, f4_l = {}, {}, {}, {}
+        for i, v in enumerate(views):
+            f4_l[v] = l_out[:, i].permute(0, 3, 1, 2)
+            f4_l[v]._glf_stack = (l_out, i)
+            atten[v] = secs[i][2]
+            mask[v], mask_bb[v] = heads[i]
+        return mask, mask_bb, atten, f4_l

@@ -845,20 +845,24 @@ def parallel_sections(fns):
 # ----------------------------------------------------------------------------------------
 # local gate (ours.py:1802-1816)
 # ----------------------------------------------------------------------------------------
+def _gate_forward(ctx, cls, ctr, f, weight: float):
+    cls, ctr, f = _contig(_chk(cls, "cls")), _contig(_chk(ctr, "ctr")), _contig(_chk(f, "f4"))
+    c = f.shape[-1]
+    rows = f.numel() // c
+    ncls = cls.shape[-1]
+    y = torch.empty_like(f)
+    a = torch.empty(rows, dtype=torch.float32, device=f.device)
+    am = torch.empty(rows, dtype=torch.int32, device=f.device)
+    check(lib.glf_gate_fwd(_p(cls), ncls, _p(ctr), _p(f), _p(y), _p(a), _p(am), weight, rows, c, _stream()), "gate_fwd")
+    ctx.save_for_backward(cls, ctr, f, a, am)
+    ctx.cfg = (rows, c, ncls, weight)
+    return y, a
+
+
 class GateFn(Function):
     @staticmethod
     def forward(ctx, cls, ctr, f, weight: float):
-        cls, ctr, f = _contig(_chk(cls, "cls")), _contig(_chk(ctr, "ctr")), _contig(_chk(f, "f4"))
-        c = f.shape[-1]
-        rows = f.numel() // c
-        ncls = cls.shape[-1]
-        y = torch.empty_like(f)
-        a = torch.empty(rows, dtype=torch.float32, device=f.device)
-        am = torch.empty(rows, dtype=torch.int32, device=f.device)
-        check(lib.glf_gate_fwd(_p(cls), ncls, _p(ctr), _p(f), _p(y), _p(a), _p(am), weight, rows, c, _stream()), "gate_fwd")
-        ctx.save_for_backward(cls, ctr, f, a, am)
-        ctx.cfg = (rows, c, ncls, weight)
-        return y
+        return _gate_forward(ctx, cls, ctr, f, weight)[0]
 
     @staticmethod
     @once_differentiable
@@ -876,6 +880,28 @@ class GateFn(Function):
 
 def local_gate(cls_logits, ctr_logits, f4, weight: float):
     return GateFn.apply(cls_logits, ctr_logits, f4, float(weight))
+
+
+class GateMapFn(GateFn):
+    """GateFn that also hands out the gate map a = sigmoid(w * max_c sigmoid(cls) * sigmoid(ctr)) as [N,1,h,w]
+    (Local_only returns it as `atten_map`, ours.py:2221-2222, 2249); the map is a non-differentiable output."""
+
+    @staticmethod
+    def forward(ctx, cls, ctr, f, weight: float):
+        y, a = _gate_forward(ctx, cls, ctr, f, weight)
+        n, h, w = f.shape[0], f.shape[1], f.shape[2]
+        amap = a.view(n, 1, h, w).clone()
+        ctx.mark_non_differentiable(amap)
+        return y, amap
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _damap):
+        return GateFn.backward(ctx, dy)
+
+
+def local_gate_with_map(cls_logits, ctr_logits, f4, weight: float):
+    return GateMapFn.apply(cls_logits, ctr_logits, f4, float(weight))
 
 
 # ----------------------------------------------------------------------------------------
@@ -948,6 +974,41 @@ class AddViewsFn(Function):
 
 def add_views(g, l):
     return AddViewsFn.apply(g, l)
+
+
+class SplitViewsFn(Function):
+    """[N,V,h,w,C] -> V contiguous [N,h,w,C] tensors (`conv_feat[:, :, i]` + `.contiguous()` of ours.py:2097, 2104)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        g = _contig(_chk(g, "stacked views"))
+        n, v, h, w, c = g.shape
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            out = torch.empty(n, h, w, c, dtype=torch.float32, device=g.device)
+            check(lib.glf_copy_frames(_p(g[:, i]), v * inner, _p(out), inner, n, inner, _stream()), "split_views")
+            outs.append(out)
+        ctx.cfg = (n, v, h, w, c)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        n, v, h, w, c = ctx.cfg
+        inner = h * w * c
+        dev = next(d.device for d in dys if d is not None)
+        dg = torch.empty(n, v, h, w, c, dtype=torch.float32, device=dev)
+        for i, d in enumerate(dys):
+            if d is None:
+                dg[:, i].zero_()
+            else:
+                check(lib.glf_copy_frames(_p(_contig(d)), inner, _p(dg[:, i]), v * inner, n, inner, _stream()), "split_views_bwd")
+        return dg
+
+
+def split_views(g):
+    return SplitViewsFn.apply(g)
 
 
 # ----------------------------------------------------------------------------------------

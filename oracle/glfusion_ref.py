@@ -302,6 +302,51 @@ class Global_and_Local(nn.Module):
         return mask, mask_bb, f4_g, f4_l
 
 
+class Global_only(Global_and_Local):
+    """ours.py:1999-2111: no local branch; the centerness heads are constructed but unused."""
+
+    def __init__(self, view_num, test_view=("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        del self.local_attn                                                        # ours.py:2040-2041
+
+    def forward(self, x):
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self.encode(x)                                                        # ours.py:2085-2090
+        g_out, _ = self.global_attn(torch.stack([f4[v] for v in self.view_num], dim=2))        # ours.py:2093-2095
+        f4_g = {v: g_out[:, :, i] for i, v in enumerate(self.view_num)}
+        mask, mask_bb = {}, {}
+        for v in self.view_num:                                                    # ours.py:2103-2108
+            mask[v] = F.interpolate(self.classifier[v](f4_g[v].contiguous()), size=hw, mode="bilinear", align_corners=False)
+            mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
+        return mask, mask_bb, f4_g, None
+
+
+class Local_only(Global_and_Local):
+    """ours.py:2113-2249: no global branch; returns (mask, mask_bb, atten_map, local fusion features)."""
+
+    def __init__(self, view_num, test_view=("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        del self.global_attn                                                       # ours.py:2151
+
+    def forward(self, x):
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self.encode(x)
+        atten, f4_local = {}, {}
+        for v in self.view_num:                                                    # ours.py:2209-2223
+            s = torch.sigmoid(self.classifier[v](f4[v]))
+            m = F.adaptive_max_pool3d(s, (1, s.shape[2], s.shape[3]))
+            c = torch.sigmoid(self.centerness[v](f4[v]))
+            atten[v] = torch.sigmoid(self.center_aware_weight * m * c)
+            f4_local[v] = f4[v] * atten[v]
+        l_out, _ = self.local_attn(torch.stack([f4_local[v] for v in self.view_num], dim=2))   # ours.py:2226-2228
+        f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
+        mask, mask_bb = {}, {}
+        for v in self.view_num:                                                    # ours.py:2242-2247
+            mask[v] = F.interpolate(self.classifier[v](f4_l[v].contiguous()), size=hw, mode="bilinear", align_corners=False)
+            mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
+        return mask, mask_bb, atten, f4_l
+
+
 # --------------------------------------------------------------------------------------
 # a8 / a9: the caller's step and metrics (main.py:87,202-243 and main.py:800-815)
 # --------------------------------------------------------------------------------------

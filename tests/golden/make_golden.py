@@ -202,6 +202,29 @@ def main() -> None:
     print("train loss", float(loss))
 
 
+def variants_fixture(ours) -> None:
+    """the two single-branch ablations, eval() outputs of the reference's own classes."""
+    views, n = ["1", "3"], 2
+    imgs = orc.closed_form_images(views, n, 112, 112)
+    for name in ("Global_only", "Local_only"):
+        model = getattr(ours, name)(views)
+        orc.closed_form_fill(model, salt=6)
+        model.eval()
+        with torch.no_grad():
+            out = model(imgs)
+        d = {"keys": np.array(list(model.state_dict().keys()))}
+        for v in views:
+            d[f"mask:{v}"] = t2n(out[0][v])
+            d[f"mask_bb:{v}"] = t2n(out[1][v])
+            third = out[2][v]
+            d[f"third:{v}"] = t2n(third) if third.shape[1] == 1 else t2n(third.reshape(-1)[torch.from_numpy(sample_idx(third.numel(), 4099))])
+            if out[3] is not None:
+                fo = out[3][v]
+                d[f"fourth:{v}"] = t2n(fo.reshape(-1)[torch.from_numpy(sample_idx(fo.numel(), 4099))])
+        np.savez_compressed(os.path.join(HERE, f"variant_{name}.npz"), **d)
+        print(name, "done", {v: float(out[0][v].abs().mean()) for v in views})
+
+
 def reference_cycle_functions():
     """Trainer.seg_cycle / Trainer.dense_seg_cycle (main.py:650-798) as callables.  main.py cannot be imported (it
     needs utils.PCGrad and the authors' data files), so the two method definitions are cut out of its syntax tree
@@ -247,7 +270,11 @@ def cycle_fixture() -> None:
 
 
 if __name__ == "__main__":
-    if not sys.argv[1:] or "cycle" in sys.argv[1:]:
+    args = sys.argv[1:]
+    if not args or "cycle" in args:
         cycle_fixture()
-    if sys.argv[1:] != ["cycle"]:
+    if not args or "variants" in args:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        variants_fixture(import_reference()[0])
+    if not args or set(args) - {"cycle", "variants"}:
         main()

@@ -306,3 +306,68 @@ def test_shared_trunk_keeps_reference_running_stats():
             assert close(buf, want[name], 1e-5), name
         checked += 1
     assert checked >= 3 * 14
+
+
+def _sample(t, k=4099):
+    flat = t.reshape(-1)
+    idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(k, flat.numel())).astype(np.int64))
+    return flat[torch.from_numpy(idx).to(flat.device)]
+
+
+@pytest.mark.parametrize("name", ["Global_only", "Local_only"])
+def test_variants_eval_vs_golden(golden_dir, name, precision):
+    """Global_only / Local_only (ours.py:1999-2249) against outputs of the reference's own classes."""
+    import glfusion_amd.models as M
+    g = np.load(os.path.join(golden_dir, f"variant_{name}.npz"))
+    views, n = ["1", "3"], 2
+    model = getattr(M, name)(views)
+    assert list(model.state_dict().keys()) == [str(k) for k in g["keys"]]
+    ref = getattr(orc, name)(views)
+    orc.closed_form_fill(ref, salt=6)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(DEV).eval()
+    imgs = {v: t.to(DEV) for v, t in orc.closed_form_images(views, n, 112, 112).items()}
+    with torch.no_grad():
+        out = model(imgs)
+    assert (out[3] is None) == (name == "Global_only")
+    for v in views:
+        assert close(out[0][v], torch.from_numpy(g[f"mask:{v}"])), v
+        assert close(out[1][v], torch.from_numpy(g[f"mask_bb:{v}"])), v
+        third = out[2][v]
+        if name == "Local_only":
+            assert tuple(third.shape) == (n, 1, 28, 28)
+            assert close(third, torch.from_numpy(g[f"third:{v}"]), 1e-4), v          # the gate map
+            assert close(_sample(out[3][v]), torch.from_numpy(g[f"fourth:{v}"]), 1e-3), v
+        else:
+            assert close(_sample(third), torch.from_numpy(g[f"third:{v}"]), 1e-3), v
+
+
+@pytest.mark.parametrize("name", ["Global_only", "Local_only"])
+def test_variants_train_step_vs_oracle(name):
+    import glfusion_amd.models as M
+    from glfusion_amd import ops
+    views, n = ["1", "3"], 4
+    ref = getattr(orc, name)(views)
+    orc.closed_form_fill(ref, salt=6)
+    orc.set_dropout(ref, 0.0)
+    model = getattr(M, name)(views)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    orc.set_dropout(model, 0.0)
+    model = model.to(DEV).train()
+    ref.train()
+    imgs = orc.closed_form_images(views, n, 112, 112)
+    tgts = orc.closed_form_targets(views, n)
+    want = sum(torch.nn.functional.binary_cross_entropy_with_logits(ref(imgs)[0][v], tgts[v], reduction="sum") for v in views)
+    want.backward()
+    pred = model({v: t.to(DEV) for v, t in imgs.items()})[0]
+    got = sum(ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
+    got.backward()
+    assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))
+    gref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    have = {k for k, p in model.named_parameters() if p.grad is not None}
+    assert have == set(gref)                                  # e.g. Global_only: no gradient reaches the centerness heads
+    attn = "global_attn" if name == "Global_only" else "local_attn"
+    top = max(float(w.norm()) for k, w in gref.items() if k.startswith(attn))
+    for k, p in model.named_parameters():
+        if k.startswith(attn) and k in gref:
+            assert float((p.grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm()) + 1e-3 * top, k

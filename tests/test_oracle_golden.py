@@ -151,3 +151,20 @@ def test_oracle_cycle_losses_match_reference_fixture(golden_dir):
             assert abs(float(loss.detach()) - float(g[key + ":loss"])) <= 1e-6 * abs(float(g[key + ":loss"]))
             ref = torch.from_numpy(g[key + ":dfeat"])
             assert float((f.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("name", ["Global_only", "Local_only"])
+def test_oracle_variants_match_reference_fixture(golden_dir, name):
+    """the single-branch ablations (ours.py:1999-2249), oracle restatement vs the reference's classes."""
+    g = np.load(os.path.join(golden_dir, f"variant_{name}.npz"))
+    views, n = ["1", "3"], 2
+    model = getattr(orc, name)(views)
+    assert list(model.state_dict().keys()) == [str(k) for k in g["keys"]]
+    orc.closed_form_fill(model, salt=6)
+    model.eval()
+    with torch.no_grad():
+        out = model(orc.closed_form_images(views, n, 112, 112))
+    for v in views:
+        for slot, key in ((0, "mask"), (1, "mask_bb")):
+            ref = torch.from_numpy(g[f"{key}:{v}"])
+            assert float((out[slot][v] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (key, v)
