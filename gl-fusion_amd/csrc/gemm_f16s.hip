@@ -296,6 +296,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     }
 
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
         if (col >= pN) return;
@@ -315,12 +316,18 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                     float v = p_alpha * acc[r] + bv;
                     if (p_accumulate) v += *dst;
                     *dst = v;
+                    cmax = fmaxf(cmax, fabsf(v));
                 }
             }
         }
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    if (args.amax_c && !p_rect) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
 
     const bool atomic = (p_split > 1) || p_accumulate;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
         if (col >= pN) return;
@@ -482,12 +490,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
             if (row < pM) {
                 float* dst = C + (long long)row * p_ldc + col;
                 const float v = p_alpha * acc[r];
-                if (atomic) atomicAdd(dst, v); else *dst = v;
+                if (atomic) atomicAdd(dst, v); else { *dst = v; cmax = fmaxf(cmax, fabsf(v)); }
             }
         }
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    if (args.amax_c && !atomic) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -709,6 +722,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
 
     const bool atomic = (p_split > 1) || p_accumulate;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
         if (col >= pN) return;
@@ -718,12 +732,17 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
             if (row < pM) {
                 float* dst = C + (long long)row * p_ldc + col;
                 const float v = p_alpha * acc[r];
-                if (atomic) atomicAdd(dst, v); else *dst = v;
+                if (atomic) atomicAdd(dst, v); else { *dst = v; cmax = fmaxf(cmax, fabsf(v)); }
             }
         }
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    if (args.amax_c && !atomic) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+    }
 }
 
 // max |x| over a [rows, cols] view (row stride ld) -> *out (non-negative floats order like their bit patterns)

@@ -20,7 +20,8 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import check, lib
-from .ops import _chk, _contig, _p, _stream, _tn_split, _ws, amax_of, colsum, gemm, split_mode, transpose2d, weight_T
+from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
+                  transpose2d, weight_T)
 
 
 class TpaviFn(Function):
@@ -46,20 +47,25 @@ class TpaviFn(Function):
         c3 = 3 * ci
         qkv = torch.empty(rows, c3, **f32)
         am_x = amax_of(x)
-        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=amax_of(Wcat))
-        am_q = amax_of(qkv)                  # one bound for the theta | phi | g column slices
+        am_q = amax_slot(dev)                # max|qkv| from the epilogue: one bound for the theta | phi | g column slices
+        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=amax_of(Wcat), amax_c=am_q)
+        set_amax(qkv, am_q)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
         bq = L * c3                                                          # batch (frame) stride inside qkv
 
         y = torch.empty(rows, ci, **f32)
         if mode == "dot":
             att = torch.empty(n, ci, ci, **f32)                              # M_n = phi_n^T g_n / L
+            am_att = amax_slot(dev)
             gemm("tn", ph, g, att, M=ci, N=ci, K=L, lda=c3, ldb=c3, ldc=ci, batch=n, bsa=bq, bsb=bq,
-                 bsc=ci * ci, alpha=1.0 / L, amax_a=am_q, amax_b=am_q)
+                 bsc=ci * ci, alpha=1.0 / L, amax_a=am_q, amax_b=am_q, amax_c=am_att)
+            set_amax(att, am_att)
             if split_mode() and ci % 32 == 0:      # y_n = theta_n M_n as NT against M_n^T (split-bf16 kernels are NT / TN only)
                 attT = transpose2d(att, ci, ci, n)
+                am_y = amax_slot(dev)
                 gemm("nt", th, attT, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci,
-                     amax_a=am_q, amax_b=amax_of(attT))
+                     amax_a=am_q, amax_b=am_att, amax_c=am_y)                  # a transpose keeps the maximum
+                set_amax(y, am_y)
                 del attT
             else:
                 gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
@@ -113,10 +119,12 @@ class TpaviFn(Function):
                                     _p(du), _p(dln_g), _p(dln_b), rows, c, _p(_ws(rows, c, dev)), _stream()), "bn_res_ln_bwd")
         # BatchNorm3d backward on w
         dwz = torch.empty(rows, c, **f32)
+        am_dwz_slot = amax_slot(dev)
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), None, _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), _stream()), "bn_bwd")
+        set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)
         dzW = (torch.empty if sp == 1 else torch.zeros)(c, ci, **f32)
@@ -127,29 +135,36 @@ class TpaviFn(Function):
         (wz_o,) = ctx.owners
         dy = torch.empty(rows, ci, **f32)
         if split:
-            gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=amax_of(zW))
+            am_dy_slot = amax_slot(dev)
+            gemm("nt", dwz, weight_T(zW, wz_o), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=amax_of(zW),
+                 amax_c=am_dy_slot)
+            set_amax(dy, am_dy_slot)
         else:
             gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
         del dwz
 
         dqkv = torch.empty(rows, c3, **f32)                   # [d theta | d phi | d g], row stride 3*ci
+        am_dq_slot = amax_slot(dev)                           # its three writers (below) all report into one slot
         dth, dph, dg = dqkv[:, 0:ci], dqkv[:, ci:2 * ci], dqkv[:, 2 * ci:]
         bs = L * ci
         am_dy = amax_of(dy)
         if mode == "dot":
             # y_n = th_n M_n ;  M_n = ph_n^T g_n / L
             gemm("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=c3, batch=n, bsa=bs, bsb=ci * ci, bsc=bq,
-                 amax_a=am_dy, amax_b=amax_of(att))
+                 amax_a=am_dy, amax_b=amax_of(att), amax_c=am_dq_slot)
             dM = torch.empty(n, ci, ci, **f32)
+            am_dM = amax_slot(dev)
             gemm("tn", th, dy, dM, M=ci, N=ci, K=L, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=bs, bsc=ci * ci,
-                 amax_a=am_q, amax_b=am_dy)
-            am_dM = amax_of(dM)
+                 amax_a=am_q, amax_b=am_dy, amax_c=am_dM)
+            set_amax(dM, am_dM)
             gemm("nt", g, dM, dph, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L,
-                 amax_a=am_q, amax_b=am_dM)
+                 amax_a=am_q, amax_b=am_dM, amax_c=am_dq_slot)
             if split:
                 dMT = transpose2d(dM, ci, ci, n)
                 gemm("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L,
-                     amax_a=am_q, amax_b=am_dM)
+                     amax_a=am_q, amax_b=am_dM, amax_c=am_dq_slot)
+                if am_dq_slot is not None:
+                    set_amax(dqkv, am_dq_slot)
                 del dMT
             else:
                 gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)

@@ -116,9 +116,11 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
          split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
-         amax_b: Optional[torch.Tensor] = None) -> None:
+         amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
-    amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library)."""
+    amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library);
+    amax_c: a slot from amax_slot() that receives max|C written| (ignored by rect / split > 1 / non-f16x3 calls -- pass
+    it only to calls that store C directly)."""
     p = GemmParams()
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
     p.taps, p.tap_mask, p.tap_stride_b, p.gather = taps, mask, tap_stride_b, gather
@@ -128,7 +130,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
     p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
     p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
-    p.amax_a, p.amax_b = _p(amax_a), _p(amax_b)
+    p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -747,7 +749,11 @@ class FanOutFn(Function):
     @staticmethod
     def forward(ctx, x, k: int):
         ctx.k = k
-        return tuple(x.view_as(x) for _ in range(k))
+        outs = tuple(x.view_as(x) for _ in range(k))
+        am = amax_of(x)                       # one measurement (or the producer's by-product) serves every alias
+        for t in outs:
+            set_amax(t, am)
+        return outs
 
     @staticmethod
     @once_differentiable

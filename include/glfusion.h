@@ -98,6 +98,10 @@ typedef struct {
     const float* amax_b;        /* and max|B| over the elements the call reads (glf_amax, or the     */
                                 /* kernel that produced the operand).  NULL: the library measures    */
                                 /* the operand itself first (one extra read of it).                  */
+    float* amax_c;              /* precision 2 only, may be NULL: device float that receives                 */
+                                /* max(*amax_c, max|C|) over the elements this call stores -- the amax of    */
+                                /* the NEXT contraction's operand for free.  Ignored (left untouched) by     */
+                                /* calls that sum partial results with atomics (rect mode, split > 1).       */
 } glf_gemm_params;
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
