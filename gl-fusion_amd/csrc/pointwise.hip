@@ -156,13 +156,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     for (int i = 0; i < 13; ++i) { const int t = tg + 4 * i; if (t < 49) dst[t * STEM_CO + co] = acc[i]; }
     if (tg == 0) dst[49 * STEM_CO + co] = accb;
 }
-__global__ void stem_wgrad_finalize(const float* __restrict__ partial, long long nblk, float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // i = t*64 + co, t in [0,50)
-    if (i >= 50 * STEM_CO) return;
+// one workgroup per tap row t (64 channels x 16 block-lanes, fixed summation order => bitwise reproducible)
+__global__ __launch_bounds__(1024) void stem_wgrad_finalize(const float* __restrict__ partial, long long nblk, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double sh[16][STEM_CO];
+    const int t = blockIdx.x, co = threadIdx.x & 63, ln = threadIdx.x >> 6;
     double s = 0;
-    for (long long b = 0; b < nblk; ++b) s += partial[b * 50 * STEM_CO + i];
-    const int t = i / STEM_CO, co = i - t * STEM_CO;
-    if (t < 49) dw[co * 49 + t] = (float)s; else if (db) db[co] = (float)s;
+    for (long long b = ln; b < nblk; b += 16) s += partial[(b * 50 + t) * STEM_CO + co];
+    sh[ln][co] = s;
+    __syncthreads();
+    if (ln == 0) {
+        for (int i = 1; i < 16; ++i) s += sh[i][co];
+        if (t < 49) dw[co * 49 + t] = (float)s; else if (db) db[co] = (float)s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -554,7 +559,7 @@ extern "C" int glf_stem7x7_wgrad(const float* x, const float* dy, float* dw, flo
     hipLaunchKernelGGL(stem_wgrad_kernel, grid, dim3(256), 0, glf::S(s), x, dy, partial, h, wdt, ho, wo, pad);
     if (int rc = glf::check_launch("stem7x7_wgrad")) return rc;
     const long long nblk = (long long)grid.x * grid.y * grid.z;
-    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((50 * STEM_CO + 255) / 256), dim3(256), 0, glf::S(s), partial, nblk, dw, db);
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3(50), dim3(1024), 0, glf::S(s), partial, nblk, dw, db);
     return glf::check_launch("stem7x7_wgrad_finalize");
 }
 
