@@ -88,7 +88,7 @@ template <int BMODE, bool GATHER>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_rows_kernel(const GemmArgs args) {
     // ---- scalar copies of the launch arguments (see GeoS) ----
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
-    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate, p_split = args.split;
+    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
     const int p_tiles_n = args.tiles_n, p_vec_a = args.vec_a, p_vec_b = args.vec_b;
     const unsigned p_tap_mask = args.tap_mask;
     const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
@@ -400,12 +400,12 @@ template <bool GATHER>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs args) {
     // ---- scalar copies of the launch arguments (see GeoS) ----
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
-    const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate, p_split = args.split;
+    const int p_accumulate = args.accumulate, p_split = args.split;
     const int p_tiles_n = args.tiles_n, p_vec_a = args.vec_a, p_vec_b = args.vec_b;
     const unsigned p_tap_mask = args.tap_mask;
     const long long p_tsb = args.tap_stride_b, p_bsa = args.bsa, p_bsb = args.bsb, p_bsc = args.bsc;
     const float p_alpha = args.alpha;
-    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B; const float* __restrict__ p_bias = args.bias;
+    const float* __restrict__ p_A = args.A; const float* __restrict__ p_B = args.B;
     float* __restrict__ p_C = args.C;
     const int g_hs = args.g.hs, g_ws = args.g.ws, g_hd = args.g.hd, g_wd = args.g.wd, g_kw = args.g.kw;
     const int g_stride = args.g.stride, g_pad = args.g.pad, g_dil = args.g.dil;

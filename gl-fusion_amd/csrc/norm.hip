@@ -41,19 +41,31 @@ struct OpColsum {         // (dy, 0)
         b = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
-struct OpBnBwd {          // (dy', dy' * xhat), dy' = dy * (y > 0) when relu
+// the forward value of one element; ONE definition so that the ReLU mask recomputed in backward (y == NULL) is the
+// mask the forward applied
+__device__ __forceinline__ float bn_val(float x, float mu, float is, float ga, float be) { return (x - mu) * is * ga + be; }
+
+struct OpBnBwd {          // (dy', dy' * xhat), dy' = dy * (y > 0) when relu; y == NULL: the mask is recomputed from x
     const float* dy; int lddy; const float* x; int ldx; const float* y; int ldy;
-    const float* mean; const float* invstd; int relu;
+    const float* mean; const float* invstd; const float* gamma; const float* beta; int relu;
     __device__ void operator()(int r, int c, float4& a, float4& b) const {
         a = *reinterpret_cast<const float4*>(dy + (long long)r * lddy + c);
-        if (relu) {
-            const float4 yy = *reinterpret_cast<const float4*>(y + (long long)r * ldy + c);
-            a.x = yy.x > 0.f ? a.x : 0.f; a.y = yy.y > 0.f ? a.y : 0.f;
-            a.z = yy.z > 0.f ? a.z : 0.f; a.w = yy.w > 0.f ? a.w : 0.f;
-        }
         const float4 xx = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        if (relu) {
+            float4 yy;
+            if (y) {
+                yy = *reinterpret_cast<const float4*>(y + (long long)r * ldy + c);
+            } else {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 be = *reinterpret_cast<const float4*>(beta + c);
+                yy = make_float4(bn_val(xx.x, mu.x, is.x, ga.x, be.x), bn_val(xx.y, mu.y, is.y, ga.y, be.y),
+                                 bn_val(xx.z, mu.z, is.z, ga.z, be.z), bn_val(xx.w, mu.w, is.w, ga.w, be.w));
+            }
+            a.x = yy.x > 0.f ? a.x : 0.f; a.y = yy.y > 0.f ? a.y : 0.f;
+            a.z = yy.z > 0.f ? a.z : 0.f; a.w = yy.w > 0.f ? a.w : 0.f;
+        }
         b = make_float4(a.x * (xx.x - mu.x) * is.x, a.y * (xx.y - mu.y) * is.y,
                         a.z * (xx.z - mu.z) * is.z, a.w * (xx.w - mu.w) * is.w);
     }
@@ -217,8 +229,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
         const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
         const float4 be = *reinterpret_cast<const float4*>(k.beta + c);
-        float4 o = make_float4((xx.x - mu.x) * is.x * ga.x + be.x, (xx.y - mu.y) * is.y * ga.y + be.y,
-                               (xx.z - mu.z) * is.z * ga.z + be.z, (xx.w - mu.w) * is.w * ga.w + be.w);
+        float4 o = make_float4(bn_val(xx.x, mu.x, is.x, ga.x, be.x), bn_val(xx.y, mu.y, is.y, ga.y, be.y),
+                               bn_val(xx.z, mu.z, is.z, ga.z, be.z), bn_val(xx.w, mu.w, is.w, ga.w, be.w));
         if (res) {
             const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + c);
             o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
@@ -242,18 +254,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
+        float4 xx = make_float4(0.f, 0.f, 0.f, 0.f), mu = xx;
+        if (training || (relu && !y)) {
+            xx = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            mu = *reinterpret_cast<const float4*>(k.mean + c);
+        }
         if (relu) {
-            const float4 yy = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            float4 yy;
+            if (y) {
+                yy = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            } else {
+                const float4 be = *reinterpret_cast<const float4*>(k.beta + c);
+                yy = make_float4(bn_val(xx.x, mu.x, is.x, ga.x, be.x), bn_val(xx.y, mu.y, is.y, ga.y, be.y),
+                                 bn_val(xx.z, mu.z, is.z, ga.z, be.z), bn_val(xx.w, mu.w, is.w, ga.w, be.w));
+            }
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
         if (dres) *reinterpret_cast<float4*>(dres + r * lddres + c) = g;
-        const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
-        const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
         float4 o;
         if (training) {
-            const float4 xx = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            const float4 mu = *reinterpret_cast<const float4*>(k.mean + c);
             const float4 s1 = *reinterpret_cast<const float4*>(sum_dy + c);
             const float4 s2 = *reinterpret_cast<const float4*>(sum_dyx + c);
             o.x = ga.x * is.x * (g.x - inv_n * (s1.x + (xx.x - mu.x) * is.x * s2.x));
@@ -425,18 +447,18 @@ extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int 
 }
 
 extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
-                          const float* mean, const float* invstd, const float* gamma,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                           int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
-    GLF_REQUIRE(!relu || y, GLF_ERR_NULL, "bn_bwd: y is required when relu != 0");
+    GLF_REQUIRE(!relu || y || beta, GLF_ERR_NULL, "bn_bwd: relu != 0 needs y (the forward output) or beta (to recompute its sign from x)");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_bwd: rows must be > 0");
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
-    if (relu) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
+    if (relu && y) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
     const int slices = n_slices_c(rows, c);
-    if (int rc = launch_colreduce(OpBnBwd{dy, lddy, x, ldx, y, ldy, mean, invstd, relu}, rows, c, workspace, glf::S(s))) return rc;
+    if (int rc = launch_colreduce(OpBnBwd{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu}, rows, c, workspace, glf::S(s))) return rc;
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
     float* s_dy = dbeta ? dbeta : sums;
@@ -445,7 +467,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     if (int rc = glf::check_launch("bn_bwd_finalize")) return rc;
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
-                       Coef{mean, invstd, gamma, nullptr}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
+                       Coef{mean, invstd, gamma, beta}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
                        1.0f / (float)rows, amax_out);
     return glf::check_launch("bn_bwd_apply");
 }

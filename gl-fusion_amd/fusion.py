@@ -122,7 +122,7 @@ class TpaviFn(Function):
         am_dwz_slot = amax_slot(dev)
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
-        check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), _p(dwz), c, None, c,
+        check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, c,
                              _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), _stream()), "bn_bwd")
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b

@@ -545,7 +545,8 @@ class BatchNormActFn(Function):
         check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
                                int(relu), _p(am), _stream()), "bn_apply")
         set_amax(y, am)
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        # without a residual the ReLU mask is recomputed from x in backward (sign of the same expression): y is not kept
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, gamma, beta if relu else None)
         ctx.cfg = (rows, c, relu, training, residual is not None)
         _last_bn[0] = (mean, invstd, rows)
         return y
@@ -553,7 +554,7 @@ class BatchNormActFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma = ctx.saved_tensors
+        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         rows, c, relu, training, has_res = ctx.cfg
         dy = _contig(dy)
         dev = dy.device
@@ -562,7 +563,7 @@ class BatchNormActFn(Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         am = amax_slot(dev)
-        check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(dx), c, _p(dres), c,
+        check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
                              _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), _stream()), "bn_bwd")
         set_amax(dx, am)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None

@@ -167,12 +167,14 @@ int glf_bn_eval_coeffs(const float* running_mean, const float* running_var, floa
 int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                  const float* mean, const float* invstd, const float* gamma, const float* beta,
                  int rows, int c, int relu, float* amax_out, glf_stream_t s);
-/* Backward.  y is the forward output (ReLU mask = y > 0) and may be NULL when relu == 0.
+/* Backward.  y is the forward output (ReLU mask = y > 0); it may be NULL when relu == 0, and also when
+ * relu != 0 and there was NO residual: the mask is then recomputed from x with beta (one tensor read less
+ * in both passes; with a residual the sign of y depends on it, so y is required).
  * training != 0: full batch-stat backward; training == 0: dx = dy*mask*gamma*invstd.
  * dres (may be NULL) receives dy*mask (gradient of the residual input).  amax_out: as in
  * glf_bn_apply, for dx. */
 int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
-               const float* mean, const float* invstd, const float* gamma,
+               const float* mean, const float* invstd, const float* gamma, const float* beta /* may be NULL with y */,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s);
 
