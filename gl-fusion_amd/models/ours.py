@@ -112,6 +112,7 @@ class _PerViewNetworks(nn.Module):
 
 class Global_and_Local(_PerViewNetworks):
     """ours.py:1708-1843."""
+    _third_output_is_f4 = False
 
     def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
         super().__init__(view_num, test_view, center_aware_weight)
@@ -126,10 +127,10 @@ class Global_and_Local(_PerViewNetworks):
         # per view: encoder, then M_cls, M_ctr and the gated local features (ours.py:1795-1816)
         def view_section(v):
             f = self._encode_view(v, x[v])
-            fa, fb, fc, fg = ops.fan_out(f, 4)              # classifier / centerness / gate / global fusion
+            fa, fb, fc, fg, *raw = ops.fan_out(f, 5 if self._third_output_is_f4 else 4)   # classifier / centerness / gate / global fusion
             cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
             ctr = self.centerness[v].forward_nhwc(fb)
-            return again, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+            return again, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight), (raw[0] if raw else None)
 
         secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
         cls_again = {v: s[0] for v, s in zip(views, secs)}
@@ -154,7 +155,15 @@ class Global_and_Local(_PerViewNetworks):
             f4_g[v]._glf_stack = (g_out, i)                 # lets ops.pooled_fusion_features pool the block once
             f4_l[v]._glf_stack = (l_out, i)
             mask[v], mask_bb[v] = heads[i]
+        if self._third_output_is_f4:                                   # Global_and_Local_cyc_nofusion (ours.py:2764)
+            return mask, mask_bb, {v: ops.from_nhwc(s[3]) for v, s in zip(views, secs)}, f4_l
         return mask, mask_bb, f4_g, f4_l
+
+
+class Global_and_Local_cyc_nofusion(Global_and_Local):
+    """ours.py:2628-2764: the same network; returns the un-fused layer4 features as third output (the cycle loss of that
+    experiment is taken on them): (mask, mask_bb, f4, f4_local_fusion)."""
+    _third_output_is_f4 = True
 
 
 class Global_only(_PerViewNetworks):

@@ -280,8 +280,10 @@ class Global_and_Local(nn.Module):
         return mask, f4
 
     def forward(self, x: Dict[str, torch.Tensor]):
+        return self._forward_from_f4(x, self.encode(x))
+
+    def _forward_from_f4(self, x, f4):
         hw = x[self.view_num[0]].shape[-2:]
-        f4 = self.encode(x)
         f4_local = {}
         for v in self.view_num:
             # ours.py:1802-1807: AdaptiveMaxPool3d((1,h,w)) on a 4-D tensor == max over the class channels
@@ -300,6 +302,15 @@ class Global_and_Local(nn.Module):
             mask[v] = F.interpolate(self.classifier[v](fused), size=hw, mode="bilinear", align_corners=False)
             mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
         return mask, mask_bb, f4_g, f4_l
+
+
+class Global_and_Local_cyc_nofusion(Global_and_Local):
+    """ours.py:2628-2764: Global_and_Local returning (mask, mask_bb, f4, f4_local_fusion)."""
+
+    def forward(self, x):
+        f4 = self.encode(x)
+        mask, mask_bb, _, f4_l = self._forward_from_f4(x, f4)
+        return mask, mask_bb, f4, f4_l
 
 
 class Global_only(Global_and_Local):

@@ -2,7 +2,7 @@ import sys, time; sys.path.insert(0,'/root/repo')
 import torch
 from glfusion_amd import ops
 from glfusion_amd.models import Global_and_Local
-ops.set_precision('bf16x6')
+ops.set_precision(sys.argv[2] if len(sys.argv)>2 else 'f16x3')
 dev=torch.device('cuda',0)
 views=['1','2','3','4','5']; T=int(sys.argv[1]) if len(sys.argv)>1 else 32; H=W=224
 torch.manual_seed(0)

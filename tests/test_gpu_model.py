@@ -314,7 +314,7 @@ def _sample(t, k=4099):
     return flat[torch.from_numpy(idx).to(flat.device)]
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion"])
 def test_variants_eval_vs_golden(golden_dir, name, precision):
     """Global_only / Local_only (ours.py:1999-2249) against outputs of the reference's own classes."""
     import glfusion_amd.models as M
