@@ -105,6 +105,35 @@ __host__ __device__ inline void tap_rect(int gather, int tap, int kw, int pad, i
     if (x1 < x0) x1 = x0;
 }
 
+// Region mode (rect = 2; 3x3 "same" convs: stride 1, pad == dil, source and destination maps of equal size).
+// Along one axis of length H the three taps have offsets (+d, 0, -d) (forward gather; mirrored for the transposed
+// one), so the axis splits into at most three bands [0, e1), [e1, e2), [e2, H) with e1 = min(d, H-d), e2 = max(d, H-d)
+// inside each of which the SET of in-range taps is constant:  band 0 = {centre, far side}, band 2 = {near side,
+// centre}, band 1 = all three when d <= H-d, the centre tap alone otherwise.  The 3 x 3 products of bands are
+// rectangles of output pixels that (a) partition the map -- every output element is stored exactly once, no atomics,
+// no zero fill -- and (b) need exactly their own taps, every one of them in range for every pixel -- no padding work.
+// band b of an axis: [lo, hi) and the 3-bit set of taps (bit t = tap index t along that axis).
+__host__ __device__ inline void axis_band(int gather, int b, int d, int h, int& lo, int& hi, unsigned& taps) {
+    int e1 = d < h - d ? d : h - d, e2 = d < h - d ? h - d : d;
+    e1 = e1 < 0 ? 0 : (e1 > h ? h : e1);
+    e2 = e2 < 0 ? 0 : (e2 > h ? h : e2);
+    lo = b == 0 ? 0 : (b == 1 ? e1 : e2);
+    hi = b == 0 ? e1 : (b == 1 ? e2 : h);
+    // forward gather: tap 0 reads y - d (valid for y >= d), tap 2 reads y + d (valid for y < h - d); transposed: mirrored
+    const unsigned first = gather == 1 ? 0b110u : 0b011u, last = gather == 1 ? 0b011u : 0b110u;
+    taps = b == 0 ? first : (b == 2 ? last : (d <= h - d ? 0b111u : 0b010u));
+}
+// region r = 3 * by + bx: rectangle and 9-bit tap mask (bit ky*3 + kx)
+__host__ __device__ inline void region_of(int gather, int r, int d, int hd, int wd, int& y0, int& y1, int& x0, int& x1, unsigned& mask) {
+    unsigned ty, tx;
+    axis_band(gather, r / 3, d, hd, y0, y1, ty);
+    axis_band(gather, r % 3, d, wd, x0, x1, tx);
+    mask = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+            if (((ty >> ky) & 1u) && ((tx >> kx) & 1u)) mask |= 1u << (ky * 3 + kx);
+}
+
 // value select (a `cond ? reg4 : make_float4(0.f, 0.f, 0.f, 0.f)` on two lvalues becomes a pointer select through scratch)
 __device__ __forceinline__ float4 keep_if(bool c, const float4 v) {
     return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);

@@ -108,7 +108,22 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     int pMe = pM;
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd;
     unsigned mask = p_tap_mask;
-    if (p_rect) {
+    if (p_rect == 2) {                              // region mode: tiles laid out region after region (see region_of)
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int y0, y1, x0, x1;
+            unsigned rm;
+            region_of(p_gather, r, g_dil, g_hd, g_wd, y0, y1, x0, x1, rm);
+            const int mt = g_nimg * (y1 - y0) * (x1 - x0);
+            const int tiles = (mt + BM8 - 1) / BM8;
+            if (!found) {
+                if (tm < tiles) { found = true; mask = rm & p_tap_mask; pMe = mt; r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0; }
+                else tm -= tiles;
+            }
+        }
+        if (!found) return;
+    } else if (p_rect) {
         for (unsigned mm = p_tap_mask; mm; mm &= mm - 1) {
             const int t = __ffs(mm) - 1;
             int y0, y1, x0, x1;
@@ -310,7 +325,15 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                     const int n = row / hw, rem = row - n * hw;
                     const int yy = rem / r_w;
                     const long long orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
-                    atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
+                    if (p_rect == 2) {                    // regions partition the output: plain store
+                        float* dst = C + orow * p_ldc + col;
+                        float v = p_alpha * acc[r] + bv;
+                        if (p_accumulate) v += *dst;
+                        *dst = v;
+                        cmax = fmaxf(cmax, fabsf(v));
+                    } else {
+                        atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
+                    }
                 } else {
                     float* dst = C + (long long)row * p_ldc + col;
                     float v = p_alpha * acc[r] + bv;
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
-    if (args.amax_c && !p_rect) {
+    if (args.amax_c && p_rect != 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
@@ -807,7 +830,15 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) 
     GemmArgs a = a0;
     a.zeros = zero_page();
     long long tiles_m = (a.M + BM8 - 1) / BM8;
-    if (a.rect) {
+    if (a.rect == 2) {
+        tiles_m = 0;
+        for (int r = 0; r < 9; ++r) {
+            int y0, y1, x0, x1;
+            unsigned rm;
+            region_of(a.gather, r, a.g.dil, a.g.hd, a.g.wd, y0, y1, x0, x1, rm);
+            tiles_m += ((long long)a.g.n_img * (y1 - y0) * (x1 - x0) + BM8 - 1) / BM8;
+        }
+    } else if (a.rect) {
         tiles_m = 0;
         for (unsigned mm = a.tap_mask; mm; mm &= mm - 1) {
             const int t = __builtin_ctz(mm);

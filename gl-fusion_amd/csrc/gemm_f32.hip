@@ -649,7 +649,13 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
-    if (p->rect) {
+    if (p->rect == 2) {                 // region mode: f16x3 kernels only (see region_of in gemm_common.h)
+        GLF_REQUIRE(glf::precision() == 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
+                    "glf_gemm_nt: rect = 2 (region mode) exists on the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands)");
+        GLF_REQUIRE(p->gather != 0 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad == p->dil && p->hs == p->hd && p->ws == p->wd &&
+                    p->batch == 1, GLF_ERR_UNSUPPORTED, "glf_gemm_nt: region mode needs a 3x3 stride-1 conv with pad == dil on equal maps, batch 1");
+        a.rect = 2;
+    } else if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
     if (glf::precision() == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
@@ -675,6 +681,7 @@ extern "C" int glf_gemm_nn(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
+    GLF_REQUIRE(p->rect != 2, GLF_ERR_UNSUPPORTED, "glf_gemm_nn: rect = 2 (region mode) is built for glf_gemm_nt on the f16x3 kernels only");
     if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nn")) return rc;
     }

@@ -317,7 +317,19 @@ def rect_fraction(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: 
 # ASPP) over the shortest reductions (Cout = 256), so once the MFMA work is cheap (f16x3) the atomics cost more
 # than the padding work they avoid unless most of it is padding: measured on the ASPP shapes, rate 12 (51 % in
 # range) is faster dense, rate 24 (18 %) faster as rectangles.
-RECT_THRESHOLD = {"fwd": 0.8, "dgrad": 0.8, "wgrad": 0.8, "dgrad_f16x3": 0.35}
+RECT_THRESHOLD = {"fwd": 0.8, "dgrad": 0.8, "wgrad": 0.8, "dgrad_f16x3": 0.35, "region": 0.8}
+
+
+def region_mode(taps: int, kh: int, stride: int, pad: int, dil: int, h: int, w: int, ho: int, wo: int, k: int, frac: float) -> bool:
+    """rect = 2 of glf_gemm_nt (f16x3 kernels): a 3x3 stride-1 "same" conv (pad == dil) is cut into <= 9 rectangles of
+    output pixels with a constant set of in-range taps -- no padding work, no atomics, no zero fill.  Used for the
+    dgrad of the ASPP rate-12 / 24 convs (2048-column outputs): 14.4 -> 11.2 ms and 7.6 -> 6.7 ms per step against
+    dense / per-tap rectangles with atomics.  Measured NOT to pay elsewhere: the forward of the same convs (256-column
+    outputs, 392 workgroups) is faster as per-tap rectangles -- the regions' blocks are fewer and of uneven length
+    (4 / 6 / 9 taps) -- and for dilations 1-4 the 5-18 % of padding work saved is less than the extra partial tiles
+    and the per-element pixel arithmetic of the epilogue cost."""
+    return (os.environ.get("GLF_REGION", "1") != "0" and int(lib.glf_get_precision()) == 2 and taps == 9 and kh == 3 and stride == 1 and pad == dil and h == ho and w == wo
+            and k % 32 == 0 and frac < RECT_THRESHOLD["region"])
 
 
 def _rect_thr(which: str) -> float:
@@ -377,9 +389,12 @@ class Conv2dFn(Function):
             if mask == 0:
                 dx = torch.zeros_like(x)
             else:
-                rect = (not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1
-                        and rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask) < _rect_thr("dgrad"))
-                dx = torch.zeros_like(x) if rect else torch.empty_like(x)
+                frac = 1.0 if plain or stride != 1 else rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask)
+                if not plain and bin(mask).count("1") > 1 and region_mode(taps, kh, stride, pad, dil, ho, wo, h, w, cout, frac):
+                    rect = 2
+                else:
+                    rect = int(not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1 and frac < _rect_thr("dgrad"))
+                dx = torch.zeros_like(x) if rect == 1 else torch.empty_like(x)
                 if split_mode() and cout % 32 == 0:
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
                     gemm("nt", dy, tap_major_T(ctx.weight_ref), dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,

@@ -93,7 +93,13 @@ typedef struct {
                                 /* mostly into the padding, i.e. ASPP): each tap runs as its own  */
                                 /* GEMM over exactly its in-range rectangle of pixels; nt/nn sum  */
                                 /* the taps with float atomics into a ZERO-FILLED C (no bias); tn */
-                                /* shortens each tap's reduction to its rectangle                 */
+                                /* shortens each tap's reduction to its rectangle.                */
+                                /* 2 (glf_gemm_nt, precision 2 only): region mode for 3x3 stride-1 */
+                                /* convs with pad == dil on equal maps: the output map is cut into */
+                                /* <= 9 rectangles inside each of which the set of in-range taps   */
+                                /* is constant; each is a GEMM over exactly its taps, every output */
+                                /* element is stored ONCE (no atomics, no zero fill, bias and      */
+                                /* accumulate allowed, no padding work)                            */
     const float* amax_a;        /* precision 2 only: DEVICE scalars holding an upper bound of max|A| */
     const float* amax_b;        /* and max|B| over the elements the call reads (glf_amax, or the     */
                                 /* kernel that produced the operand).  NULL: the library measures    */
