@@ -201,11 +201,17 @@ def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
         t._glf_amax = (t._version, t.data_ptr(), amax)
 
 
+_TN_TARGET = int(os.environ.get("GLF_TN_TARGET", "0"))      # 0: per precision (below)
+
+
 def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     """Reduction slices for the TN (wgrad) kernel: fill ~4 waves of 512 resident workgroups,
     keep >= 16 K-tiles (512 rows) per slice."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128) * max(ntaps, 1) * batch
-    want = max(1, (2048 + tiles - 1) // tiles)
+    # workgroups to aim for: 2048 128x128 tiles on the fp32 / bf16x6 kernels (two per CU); the f16x3 kernel has 256-wide
+    # tiles, one workgroup per CU, and shares the chip with other streams: 1024 measured best (293.5 vs 299.2 ms / step)
+    target = _TN_TARGET or (1024 if int(lib.glf_get_precision()) == 2 else 2048)
+    want = max(1, (target + tiles - 1) // tiles)
     cap = max(1, rows // 512)
     return int(max(1, min(want, cap, 65535 // max(batch, 1))))
 
