@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
         ("batch_stride_a", C.c_int64), ("batch_stride_b", C.c_int64), ("batch_stride_c", C.c_int64),
         ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32), ("rect", C.c_int32),
         ("amax_a", C.c_void_p), ("amax_b", C.c_void_p), ("amax_c", C.c_void_p),
+        ("colstats", C.c_void_p),
     ]
 
 

@@ -21,6 +21,7 @@ struct GemmArgs {
     const float* amax_a; const float* amax_b;   // f16x3 only: device scalars bounding max|A|, max|B| (null = no scaling)
     const float* zeros;                         // f16x3 only: device page of ZERO_PAGE_FLOATS zeros
     float* amax_c;                              // f16x3 only: receives max(*amax_c, max|C written|) (null = not wanted)
+    double* colstats;                           // f16x3 NT only: [2][N] += column sums of C and of C^2 (null = not wanted)
 };
 constexpr int ZERO_PAGE_FLOATS = 1 << 18;
 
@@ -172,7 +173,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
-    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats;
     return a;
 }
 

@@ -312,7 +312,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     float cmax = 0.f;
-    auto emit = [&](const f32x16& acc, int ti, int tj) {
+    const bool p_colstats = args.colstats != nullptr;
+    // cs / cq: this lane's column sum and sum of squares over the rows it stores (colstats)
+    auto emit = [&](const f32x16& acc, int ti, int tj, double& cs, double& cq) {
         const int col = tn * BN + wn + 32 * tj + col_l;
         if (col >= pN) return;
         const float bv = p_bias ? p_bias[col] : 0.f;
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                         if (p_accumulate) v += *dst;
                         *dst = v;
                         cmax = fmaxf(cmax, fabsf(v));
+                        if (p_colstats) { const double vd = (double)v; cs += vd; cq = fma(vd, vd, cq); }
                     } else {
                         atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
                     }
@@ -340,16 +343,32 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                     if (p_accumulate) v += *dst;
                     *dst = v;
                     cmax = fmaxf(cmax, fabsf(v));
+                    if (p_colstats) { const double vd = (double)v; cs += vd; cq = fma(vd, vd, cq); }
                 }
             }
         }
     };
-    emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
-    emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    // in double from the first product on: E[x^2] - E[x]^2 cancels badly when a channel's values are close together (the
+    // ASPP pooled branch: N nearly equal frame averages), fp32 partial sums cost 4e-4 on its BatchNorm output there
+    double cs0 = 0.0, cq0 = 0.0, cs1 = 0.0, cq1 = 0.0;
+    emit(c00 + m00 * 0x1p-11f, 0, 0, cs0, cq0); emit(c01 + m01 * 0x1p-11f, 0, 1, cs1, cq1);
+    emit(c10 + m10 * 0x1p-11f, 1, 0, cs0, cq0); emit(c11 + m11 * 0x1p-11f, 1, 1, cs1, cq1);
     if (args.amax_c && p_rect != 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+    }
+    if (args.colstats && p_rect != 1) {
+        // lanes l and l + 32 hold the two row groups of the same column: fold them, then one f64 atomic per column
+        // and statistic from this wave's 64 rows
+        double* st = args.colstats;
+        cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+        cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+        if (lane < 32) {
+            const int col0 = tn * BN + wn + col_l, col1 = col0 + 32;
+            if (col0 < pN) { atomicAdd(st + col0, cs0); atomicAdd(st + pN + col0, cq0); }
+            if (col1 < pN) { atomicAdd(st + col1, cs1); atomicAdd(st + pN + col1, cq1); }
+        }
     }
 }
 

@@ -658,6 +658,8 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     } else if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
+    GLF_REQUIRE(!p->colstats || (glf::precision() == 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
+                "glf_gemm_nt: colstats is honoured by the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands, no rect = 1, batch 1)");
     if (glf::precision() == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
     if (glf::precision() == 2 && glf::f16s_rows_ok(a)) {
         if (int rc = self_amax(a, p, false, glf::S(stream))) return rc;
@@ -681,6 +683,7 @@ extern "C" int glf_gemm_nn(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
+    GLF_REQUIRE(!p->colstats, GLF_ERR_UNSUPPORTED, "glf_gemm_nn: colstats is honoured by glf_gemm_nt on the f16x3 kernels only");
     GLF_REQUIRE(p->rect != 2, GLF_ERR_UNSUPPORTED, "glf_gemm_nn: rect = 2 (region mode) is built for glf_gemm_nt on the f16x3 kernels only");
     if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nn")) return rc;
@@ -697,6 +700,7 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
     if (int rc = glf::ensure_init()) return rc;
     if (int rc = validate(p, A, B, C)) return rc;
     GLF_REQUIRE(p->gather != 2, GLF_ERR_UNSUPPORTED, "gemm_tn: transposed gather is not defined for the reduction form");
+    GLF_REQUIRE(!p->colstats, GLF_ERR_UNSUPPORTED, "gemm_tn: colstats is honoured by glf_gemm_nt on the f16x3 kernels only");
     if (p->gather) GLF_REQUIRE((long long)p->n_img * p->hd * p->wd == p->K, GLF_ERR_BAD_SHAPE,
                                "gemm_tn: K (%d rows) != n_img*hd*wd", p->K);
     GemmArgs a = make_args(A, B, nullptr, C, p);

@@ -425,6 +425,17 @@ extern "C" int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps,
     return glf::check_launch("bn_stats_finalize");
 }
 
+extern "C" int glf_bn_stats_from_sums(const double* sums, int rows, int c, float eps, float momentum, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(sums && mean && invstd, GLF_ERR_NULL, "bn_stats_from_sums: null argument");
+    GLF_REQUIRE(rows > 0 && c > 0, GLF_ERR_BAD_SHAPE, "bn_stats_from_sums: rows and c must be > 0");
+    GLF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GLF_ERR_NULL, "bn_stats_from_sums: running_mean/var must both be set or both NULL");
+    hipLaunchKernelGGL(bn_stats_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), sums, 1, c, rows,
+                       eps, momentum, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
+    return glf::check_launch("bn_stats_from_sums");
+}
+
 extern "C" int glf_bn_eval_coeffs(const float* rm, const float* rv, float eps, float* mean, float* invstd, int c, glf_stream_t s) {
     GLF_REQUIRE(rm && rv && mean && invstd, GLF_ERR_NULL, "bn_eval_coeffs: null argument");
     GLF_REQUIRE(c > 0, GLF_ERR_BAD_SHAPE, "bn_eval_coeffs: c must be > 0");

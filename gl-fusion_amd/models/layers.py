@@ -8,6 +8,8 @@ row-major [N*H*W, C] matrices.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -28,21 +30,21 @@ class Conv2d(nn.Conv2d):
             raise RuntimeError("glfusion_amd: only groups=1, zero padding convolutions are on the path")
         return _one(self.stride), _one(self.padding), _one(self.dilation)
 
-    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+    def forward_nhwc(self, x: torch.Tensor, colstats=None) -> torch.Tensor:
         stride, pad, dil = self._geom()
         if self.in_channels == 1 and self.kernel_size == (7, 7) and stride == 1 and dil == 1:
             return ops.stem7x7(x, self.weight, self.bias, pad)          # models/_utils.py:192
         if self.in_channels % 4 != 0:
             raise RuntimeError(f"glfusion_amd: conv with Cin={self.in_channels} is not on the path")
-        return ops.conv2d(x, self.weight, self.bias, stride, pad, dil)
+        return ops.conv2d(x, self.weight, self.bias, stride, pad, dil, colstats)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
-    def forward_nhwc(self, x, relu: bool = False, residual=None):
-        return ops.batch_norm_act(x, self, relu, residual)
+    def forward_nhwc(self, x, relu: bool = False, residual=None, sums=None):
+        return ops.batch_norm_act(x, self, relu, residual, sums)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
@@ -78,6 +80,17 @@ class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
         return ops.from_nhwc(ops.global_avgpool(ops.to_nhwc(x)))
 
 
+FUSE_BN_STATS = os.environ.get("GLF_FUSE_BN_STATS", "1") != "0"
+
+
 def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
-    """conv -> BatchNorm (train or eval) -> (+residual) -> (ReLU) on NHWC tensors."""
+    """conv -> BatchNorm (train or eval) -> (+residual) -> (ReLU) on NHWC tensors.  In train() the batch statistics
+    (sum x, sum x^2 per channel) are accumulated by the conv's own epilogue where the kernel supports it, which saves the
+    separate statistics pass over the conv output."""
+    training = bn.training or bn.running_mean is None
+    if training and FUSE_BN_STATS and not (conv.in_channels == 1 and conv.kernel_size == (7, 7)):
+        stride, pad, dil = conv._geom()
+        if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2]):
+            sums = torch.zeros(2, conv.out_channels, dtype=torch.float64, device=x.device)
+            return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums)
     return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual)

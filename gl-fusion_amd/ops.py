@@ -116,7 +116,8 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          tap_stride_b: int = 0, gather: int = 0, geo: Optional[Tuple[int, ...]] = None, batch: int = 1,
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
          split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
-         amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None) -> None:
+         amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None,
+         colstats: Optional[torch.Tensor] = None) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
     amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library);
     amax_c: a slot from amax_slot() that receives max|C written| (ignored by rect / split > 1 / non-f16x3 calls -- pass
@@ -131,6 +132,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
     p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
+    p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -352,7 +354,7 @@ class Conv2dFn(Function):
     """F.conv2d on [N,H,W,Cin] with torch-layout weights [Cout,Cin,kh,kw] (groups = 1)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int):
+    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int, colstats=None):
         _chk(x, "conv input"); _chk(weight, "conv weight")
         x = _contig(x)
         n, h, w, cin = x.shape
@@ -372,9 +374,11 @@ class Conv2dFn(Function):
                 and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("fwd"))
         if rect:
             y.zero_()
+            if colstats is not None:
+                raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
-             amax_a=amax_of(x), amax_b=amax_of(weight))
+             amax_a=amax_of(x), amax_b=amax_of(weight), colstats=colstats)
         ctx.save_for_backward(x, wt)
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
@@ -431,11 +435,31 @@ class Conv2dFn(Function):
                 check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, rows_o, cout)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1):
-    return Conv2dFn.apply(x, weight, bias, stride, pad, dil)
+def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1, colstats=None):
+    return Conv2dFn.apply(x, weight, bias, stride, pad, dil, colstats)
+
+
+def conv_stats_fusable(weight, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
+    """True when conv2d(..., colstats=) is honoured: f16x3 kernels (Cin % 32 == 0, Cout % 4 == 0) and the conv is not
+    one that runs as per-tap rectangles with atomics (ASPP rate 12 / 24 forward)."""
+    if int(lib.glf_get_precision()) != 2:
+        return False
+    cout, cin, kh, kw = weight.shape
+    if cin % 32 != 0 or cout % 4 != 0:
+        return False
+    taps = kh * kw
+    if taps == 1 and stride == 1 and pad == 0:
+        return True
+    ho, wo = _conv_out(h, kh, stride, pad, dil), _conv_out(w, kw, stride, pad, dil)
+    if ho <= 0 or wo <= 0:
+        return False
+    mask = tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+    rect = (taps > 1 and stride == 1 and bin(mask).count("1") > 1
+            and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("fwd"))
+    return not rect
 
 
 class ConvCatFn(Function):
@@ -544,7 +568,7 @@ _last_bn = [None]          # (mean, invstd, rows) of the most recent BatchNormAc
 class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool,
-                momentum: float, eps: float, relu: bool):
+                momentum: float, eps: float, relu: bool, sums=None):
         _chk(x, "bn input"); _chk(gamma, "bn weight"); _chk(beta, "bn bias")
         x = _contig(x)
         c = x.shape[-1]
@@ -552,7 +576,10 @@ class BatchNormActFn(Function):
         dev = x.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
-        if training:
+        if training and sums is not None:        # (sum x, sum x^2) came out of the producing contraction's epilogue
+            check(lib.glf_bn_stats_from_sums(_p(sums), rows, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                                             _p(running_var), _p(nbt), _stream()), "bn_stats_from_sums")
+        elif training:
             check(lib.glf_bn_stats(_p(x), c, rows, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
                                    _p(nbt), _p(_ws(rows, c, dev)), _stream()), "bn_stats")
         else:
@@ -587,7 +614,7 @@ class BatchNormActFn(Function):
         check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
                              _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), _stream()), "bn_bwd")
         set_amax(dx, am)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
 
 
 # When a list, every train-mode batch_norm_act call appends (module, batch mean, batch invstd, rows): enough to
@@ -609,7 +636,7 @@ def replay_bn_updates(records) -> None:
             bn.num_batches_tracked.add_(1)
 
 
-def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None):
+def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None):
     """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
     optionally fused with a residual add and ReLU."""
     training = bn.training or bn.running_mean is None
@@ -624,7 +651,7 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
                              bn.running_mean if (track or not training) else None,
                              bn.running_var if (track or not training) else None,
                              bn.num_batches_tracked if track else None,
-                             training, momentum, float(bn.eps), relu)
+                             training, momentum, float(bn.eps), relu, sums if training else None)
     if BN_TAP is not None and track:
         BN_TAP.append((bn,) + _last_bn[0])
     return y

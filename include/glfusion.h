@@ -108,6 +108,11 @@ typedef struct {
                                 /* max(*amax_c, max|C|) over the elements this call stores -- the amax of    */
                                 /* the NEXT contraction's operand for free.  Ignored (left untouched) by     */
                                 /* calls that sum partial results with atomics (rect mode, split > 1).       */
+    double* colstats;           /* glf_gemm_nt, precision 2 only, may be NULL: DEVICE doubles [2][N], zero-filled by   */
+                                /* the caller; the epilogue adds the column sums of the stored C and of C^2 --   */
+                                /* the BatchNorm batch statistics of a conv output without a pass over it        */
+                                /* (finish with glf_bn_stats_from_sums).  A call that cannot honour it (exact    */
+                                /* kernels, rect = 1) fails with GLF_ERR_UNSUPPORTED instead of ignoring it.     */
 } glf_gemm_params;
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
@@ -164,6 +169,10 @@ int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps, float mome
                  float* mean, float* invstd, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked /* may be NULL; += 1 */,
                  double* workspace, glf_stream_t s);
+/* The same outputs / running-statistics update as glf_bn_stats from per-channel sums[2][c] = (sum x, sum x^2) over
+ * `rows` rows -- the colstats a contraction epilogue accumulated. */
+int glf_bn_stats_from_sums(const double* sums, int rows, int c, float eps, float momentum, float* mean, float* invstd,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, glf_stream_t s);
 /* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  For eval() pass running_mean and
  * 1/sqrt(running_var+eps) (glf_bn_eval_coeffs).  In-place (y == x) allowed.
  * amax_out (may be NULL): device float that must hold 0 (or any lower bound) before the call and

@@ -304,3 +304,36 @@ def test_softmax_rows(ops):
     from glfusion_amd._lib import lib, check
     check(lib.glf_softmax_rows(ops._p(xd), 37, 301, ops._stream()))
     assert close(xd, torch.softmax(x, -1), 1e-6)
+
+
+@pytest.mark.parametrize("cfg", [(3, 9, 11, 64, 96, 1, 1, 0, 1), (2, 28, 28, 32, 160, 3, 1, 2, 2), (2, 28, 28, 64, 40, 3, 1, 36, 36),
+                                 (2, 55, 55, 32, 48, 3, 2, 1, 1), (5, 1, 1, 64, 32, 1, 1, 0, 1)])
+def test_conv_epilogue_column_statistics(ops, cfg):
+    """f16x3: the conv epilogue accumulates (sum y, sum y^2) per output channel; BatchNorm fed with them must equal
+    BatchNorm computing its statistics with its own pass over y."""
+    n, h, w, cin, cout, k, stride, pad, dil = cfg
+    ops.set_precision("f16x3")
+    try:
+        x = rnd(n, h, w, cin, seed=21).to(DEV)
+        wt = (rnd(cout, cin, k, k, seed=22) / np.sqrt(cin * k * k)).to(DEV)
+        assert ops.conv_stats_fusable(wt, stride, pad, dil, h, w)
+        sums = torch.zeros(2, cout, dtype=torch.float64, device=DEV)
+        y = ops.conv2d(x, wt, None, stride, pad, dil, sums)
+        y2 = y.double().reshape(-1, cout)
+        assert torch.allclose(sums[0], y2.sum(0), rtol=1e-6, atol=1e-6 * float(y2.abs().sum(0).max()))
+        assert torch.allclose(sums[1], (y2 * y2).sum(0), rtol=1e-6)
+        bn_a, bn_b = torch.nn.BatchNorm2d(cout).to(DEV).train(), torch.nn.BatchNorm2d(cout).to(DEV).train()
+        za = ops.batch_norm_act(y, bn_a, True, None, sums)
+        zb = ops.batch_norm_act(y, bn_b, True, None)
+        assert torch.allclose(za, zb, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6) and torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-7)
+        # a conv that runs as per-tap rectangles cannot honour it and says so
+        wr = (rnd(32, 64, 3, 3, seed=23) / 24.0).to(DEV)
+        assert not ops.conv_stats_fusable(wr, 1, 12, 12, 28, 28)
+        with pytest.raises(RuntimeError):
+            ops.conv2d(rnd(2, 28, 28, 64, seed=24).to(DEV), wr, None, 1, 12, 12, torch.zeros(2, 32, dtype=torch.float64, device=DEV))
+        ops.set_precision("f32")
+        with pytest.raises(RuntimeError, match="colstats"):
+            ops.conv2d(x, wt, None, stride, pad, dil, torch.zeros(2, cout, dtype=torch.float64, device=DEV))
+    finally:
+        ops.set_precision("f32")
