@@ -11,7 +11,7 @@ from torch import nn
 
 from .. import ops
 from ..fusion import tpavi_forward
-from .layers import Conv2d, conv_bn_act
+from .layers import Conv2d, ReLU, conv_bn_act
 from .segmentation import deeplabv3_resnet50_iekd
 
 
@@ -119,6 +119,11 @@ class Global_and_Local(_PerViewNetworks):
         self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
         self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
+    def _fuse(self, g_out, l_out):
+        """f4_fusion[v] = global + local (ours.py:1833-1834); returns a function (view index, view) -> [N,h,w,C]."""
+        fused = ops.add_views(g_out, l_out)
+        return lambda i, v: fused[i]
+
     def forward(self, x: Dict[str, torch.Tensor]):
         views = list(self.view_num)
         hw = x[views[0]].shape[-2:]
@@ -140,10 +145,10 @@ class Global_and_Local(_PerViewNetworks):
         g_out, l_out = ops.parallel_sections([
             lambda: self.global_attn.forward_nvhwc(ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
             lambda: self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))])
-        fused = ops.add_views(g_out, l_out)                                                     # ours.py:1833-1834
+        fused = self._fuse(g_out, l_out)                                                        # ours.py:1833-1834
 
         def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second
-            m = ops.bilinear_up(self.classifier[v].forward_nhwc(fused[i]), ho, wo)              # ours.py:1837-1838
+            m = ops.bilinear_up(self.classifier[v].forward_nhwc(fused(i, v)), ho, wo)           # ours.py:1837-1838
             mb = ops.bilinear_up(self.classifier[v].forward_nhwc_replay(cls_again[v]), ho, wo)  # ours.py:1840-1841, on f4[v]
             return m, mb
 
@@ -164,6 +169,28 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
     """ours.py:2628-2764: the same network; returns the un-fused layer4 features as third output (the cycle loss of that
     experiment is taken on them): (mask, mask_bb, f4, f4_local_fusion)."""
     _third_output_is_f4 = True
+
+
+class Global_and_Local_conv_merge(Global_and_Local):
+    """ours.py:2766-2886: the two fusion outputs are merged by a learned per-view `merge` = Conv2d(4096, 2048, 1) + ReLU
+    over their channel concatenation instead of being added.  The concatenation is never materialised (the 1x1 conv
+    runs as two accumulated K = 2048 contractions over the two fusion blocks' per-view slices)."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        _PerViewNetworks.__init__(self, view_num, test_view, center_aware_weight)
+        self.merge = nn.ModuleDict()                                    # registered before the fusion blocks, as in the reference
+        for view in self.view_num:
+            self.merge[view] = nn.Sequential(Conv2d(2048 * 2, 2048, kernel_size=1), ReLU())
+        self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
+        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
+
+    def _fuse(self, g_out, l_out):
+        gs, ls = ops.split_views(g_out), ops.split_views(l_out)
+
+        def fused(i, v):                                                # ours.py:2860-2862: cat(dim=1) -> merge
+            conv = self.merge[v][0]
+            return ops.relu(ops.conv1x1_cat(conv.weight, [gs[i], ls[i]], conv.bias))
+        return fused
 
 
 class Global_only(_PerViewNetworks):

@@ -467,7 +467,7 @@ class ConvCatFn(Function):
     the concat (ASPP project, deeplabv3.py:153-165): y = sum_k x_k @ W[:, slice_k]^T."""
 
     @staticmethod
-    def forward(ctx, weight, *xs):
+    def forward(ctx, weight, bias, *xs):
         _chk(weight, "weight")
         xs = [_contig(_chk(t, "input")) for t in xs]
         cout, ctot = weight.shape[0], weight.shape[1]
@@ -478,13 +478,14 @@ class ConvCatFn(Function):
         for i, t in enumerate(xs):
             ck = t.shape[-1]
             gemm("nt", t, w2[:, off:], y, M=rows, N=cout, K=ck, lda=ck, ldb=ctot, ldc=cout, accumulate=i > 0,
-                 amax_a=amax_of(t), amax_b=amax_of(weight))
+                 bias=bias if i == 0 else None, amax_a=amax_of(t), amax_b=amax_of(weight))
             off += ck
         if off != ctot:
             raise RuntimeError(f"conv_cat: inputs have {off} channels in total, weight expects {ctot}")
         ctx.save_for_backward(w2, *xs)
         ctx.wshape = tuple(weight.shape)
         ctx.weight_ref = weight
+        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
@@ -498,12 +499,13 @@ class ConvCatFn(Function):
         dw = None
         if ctx.needs_input_grad[0]:
             dw = (torch.empty if split == 1 else torch.zeros)(cout, ctot, dtype=torch.float32, device=dy.device)
+        db = colsum(dy, rows, cout) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         grads = []
         off = 0
         am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
         for i, t in enumerate(xs):
             ck = t.shape[-1]
-            if ctx.needs_input_grad[1 + i]:
+            if ctx.needs_input_grad[2 + i]:
                 dx = torch.empty_like(t)
                 if split_mode() and cout % 32 == 0:
                     wT = weight_T(w2, ctx.weight_ref)                     # [ctot][cout]
@@ -517,11 +519,11 @@ class ConvCatFn(Function):
                 gemm("tn", dy, t, dw[:, off:], M=cout, N=ck, K=rows, lda=cout, ldb=ck, ldc=ctot, split=split,
                      amax_a=am_dy, amax_b=amax_of(t))
             off += ck
-        return (dw.view(ctx.wshape) if dw is not None else None, *grads)
+        return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
 
 
-def conv1x1_cat(weight, xs: Sequence[torch.Tensor]):
-    return ConvCatFn.apply(weight, *xs)
+def conv1x1_cat(weight, xs: Sequence[torch.Tensor], bias=None):
+    return ConvCatFn.apply(weight, bias, *xs)
 
 
 # ----------------------------------------------------------------------------------------

@@ -279,6 +279,9 @@ class Global_and_Local(nn.Module):
                 for v in self.view_num}
         return mask, f4
 
+    def fuse(self, v, g, l):
+        return g + l                                                               # ours.py:1833-1834
+
     def forward(self, x: Dict[str, torch.Tensor]):
         return self._forward_from_f4(x, self.encode(x))
 
@@ -298,7 +301,7 @@ class Global_and_Local(nn.Module):
         f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
         mask, mask_bb = {}, {}
         for v in self.view_num:                                                    # ours.py:1833-1841
-            fused = f4_g[v] + f4_l[v]
+            fused = self.fuse(v, f4_g[v], f4_l[v])
             mask[v] = F.interpolate(self.classifier[v](fused), size=hw, mode="bilinear", align_corners=False)
             mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
         return mask, mask_bb, f4_g, f4_l
@@ -311,6 +314,20 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
         f4 = self.encode(x)
         mask, mask_bb, _, f4_l = self._forward_from_f4(x, f4)
         return mask, mask_bb, f4, f4_l
+
+
+class Global_and_Local_conv_merge(Global_and_Local):
+    """ours.py:2766-2886: fusion = merge[v](cat([global, local], dim=1)) with merge = Conv2d(4096, 2048, 1) + ReLU."""
+
+    def __init__(self, view_num, test_view=("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        g, l = self.global_attn, self.local_attn
+        del self.global_attn, self.local_attn
+        self.merge = nn.ModuleDict({v: nn.Sequential(nn.Conv2d(2048 * 2, 2048, kernel_size=1), nn.ReLU()) for v in self.view_num})
+        self.global_attn, self.local_attn = g, l                                   # registration order of ours.py:2781-2806
+
+    def fuse(self, v, g, l):
+        return self.merge[v](torch.cat([g, l], dim=1))                             # ours.py:2860-2862
 
 
 class Global_only(Global_and_Local):

@@ -314,7 +314,7 @@ def _sample(t, k=4099):
     return flat[torch.from_numpy(idx).to(flat.device)]
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge"])
 def test_variants_eval_vs_golden(golden_dir, name, precision):
     """Global_only / Local_only (ours.py:1999-2249) against outputs of the reference's own classes."""
     import glfusion_amd.models as M
@@ -342,7 +342,7 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
             assert close(_sample(third), torch.from_numpy(g[f"third:{v}"]), 1e-3), v
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge"])
 def test_variants_train_step_vs_oracle(name):
     import glfusion_amd.models as M
     from glfusion_amd import ops
@@ -366,7 +366,7 @@ def test_variants_train_step_vs_oracle(name):
     gref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
     have = {k for k, p in model.named_parameters() if p.grad is not None}
     assert have == set(gref)                                  # e.g. Global_only: no gradient reaches the centerness heads
-    attn = "global_attn" if name == "Global_only" else "local_attn"
+    attn = "local_attn" if name == "Local_only" else ("merge" if name.endswith("conv_merge") else "global_attn")
     top = max(float(w.norm()) for k, w in gref.items() if k.startswith(attn))
     for k, p in model.named_parameters():
         if k.startswith(attn) and k in gref:
