@@ -337,3 +337,47 @@ def test_conv_epilogue_column_statistics(ops, cfg):
             ops.conv2d(x, wt, None, stride, pad, dil, torch.zeros(2, cout, dtype=torch.float64, device=DEV))
     finally:
         ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("sa,sb", [(1.0, 1.0), (1e-12, 1e9), (3e7, 1e-3), (1e-30, 1e20)])
+def test_f16x3_contraction_accuracy_over_the_fp32_range(sa, sb):
+    """The scaled split-fp16 kernels against fp64 for operands anywhere in the fp32 exponent range, with one operand
+    row 1e6 below its tensor's maximum (precision is relative to each ELEMENT down to 2^-27 of the operand maximum),
+    for caller-supplied maxima (exact, and an 8x loose upper bound) and library-measured ones."""
+    from glfusion_amd import ops
+    from glfusion_amd._lib import lib
+    M, N, K = 512, 256, 4096
+    a = rnd(M, K, seed=31) * sa
+    b = rnd(N, K, seed=32) * sb
+    a[5] *= 1e-6
+    ref = a.double() @ b.double().T
+    ad, bd = a.to(DEV), b.to(DEV)
+    at, bt = a.T.contiguous().to(DEV), b.T.contiguous().to(DEV)        # [K, M], [K, N] for the reduction-over-rows form
+    ops.set_precision("f32")
+    c32 = torch.empty(M, N, device=DEV)
+    ops.gemm("nt", ad, bd, c32, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    e32 = float((c32.double().cpu() - ref).abs().max() / ref.abs().max())
+    ops.set_precision("f16x3")
+    try:
+        am = torch.zeros(2, device=DEV)
+        lib.glf_amax(ad.data_ptr(), 1, ad.numel(), ad.numel(), am[0:].data_ptr(), None)
+        lib.glf_amax(bd.data_ptr(), 1, bd.numel(), bd.numel(), am[1:].data_ptr(), None)
+        assert abs(float(am[0]) - float(a.abs().max())) == 0 and abs(float(am[1]) - float(b.abs().max())) == 0
+        for maxima in (None, am, am * 8.0):
+            kw = {} if maxima is None else dict(amax_a=maxima[0:], amax_b=maxima[1:])
+            c = torch.empty(M, N, device=DEV)
+            ops.gemm("nt", ad, bd, c, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+            err = float((c.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err <= max(3 * e32, 1.5e-6), (err, e32)
+            row5 = float((c[5].double().cpu() - ref[5]).abs().max() / ref[5].abs().max())
+            assert row5 <= 3e-6, row5                                   # the small row keeps its own relative accuracy
+            ct = torch.zeros(M, N, device=DEV)
+            ops.gemm("tn", at, bt, ct, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=2, **kw)
+            errt = float((ct.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert errt <= max(3 * e32, 1.5e-6), (errt, e32)
+        slot = torch.zeros(1, device=DEV)
+        c = torch.empty(M, N, device=DEV)
+        ops.gemm("nt", ad, bd, c, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=am[0:], amax_b=am[1:], amax_c=slot)
+        assert float(slot) == float(c.abs().max())                       # epilogue by-product: max |C|
+    finally:
+        ops.set_precision("f32")
