@@ -124,11 +124,15 @@ __host__ __device__ inline void axis_band(int gather, int b, int d, int h, int& 
     const unsigned first = gather == 1 ? 0b110u : 0b011u, last = gather == 1 ? 0b011u : 0b110u;
     taps = b == 0 ? first : (b == 2 ? last : (d <= h - d ? 0b111u : 0b010u));
 }
-// region r = 3 * by + bx: rectangle and 9-bit tap mask (bit ky*3 + kx)
+// region number r (0..8) in DISPATCH order: the centre (all its taps in range: the longest blocks) first, then the four
+// edges, then the corners, so that the last, partly filled round of workgroups consists of the shortest blocks.
+// Rectangle and 9-bit tap mask (bit ky*3 + kx).
 __host__ __device__ inline void region_of(int gather, int r, int d, int hd, int wd, int& y0, int& y1, int& x0, int& x1, unsigned& mask) {
+    // (by, bx) packed as by*3 + bx for r = 0..8: centre, edges, corners
+    const int cell = (int)((0x8620'7531'4ull >> (4 * r)) & 0xf);
     unsigned ty, tx;
-    axis_band(gather, r / 3, d, hd, y0, y1, ty);
-    axis_band(gather, r % 3, d, wd, x0, x1, tx);
+    axis_band(gather, cell / 3, d, hd, y0, y1, ty);
+    axis_band(gather, cell % 3, d, wd, x0, x1, tx);
     mask = 0;
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx)
