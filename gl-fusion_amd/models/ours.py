@@ -119,6 +119,11 @@ class Global_and_Local(_PerViewNetworks):
         self.global_attn = TPAVIModule(in_channels=2048, mode="dot")
         self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
+    def _attend(self, block, stacked):
+        """One fusion block over the stacked views [N,V,h,w,C] (ours.py:1819-1830): attention among the V*h*w positions
+        of each frame."""
+        return block.forward_nvhwc(stacked)
+
     def _fuse(self, g_out, l_out):
         """f4_fusion[v] = global + local (ours.py:1833-1834); returns a function (view index, view) -> [N,h,w,C]."""
         fused = ops.add_views(g_out, l_out)
@@ -143,8 +148,8 @@ class Global_and_Local(_PerViewNetworks):
         f4_local = {v: s[2] for v, s in zip(views, secs)}
         # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
         g_out, l_out = ops.parallel_sections([
-            lambda: self.global_attn.forward_nvhwc(ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
-            lambda: self.local_attn.forward_nvhwc(ops.stack_views([f4_local[v] for v in views]))])
+            lambda: self._attend(self.global_attn, ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
+            lambda: self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))])
         fused = self._fuse(g_out, l_out)                                                        # ours.py:1833-1834
 
         def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second
@@ -169,6 +174,28 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
     """ours.py:2628-2764: the same network; returns the un-fused layer4 features as third output (the cycle loss of that
     experiment is taken on them): (mask, mask_bb, f4, f4_local_fusion)."""
     _third_output_is_f4 = True
+
+
+class Global_and_Local_Temporal(Global_and_Local):
+    """ours.py:1846-1997: forward(x, is_video).  With is_video the T frames of a clip are folded into the attention
+    axis -- one "frame" of T*V*h*w positions (L = 37 632 at T = 16) -- so every position attends across views AND time.
+    As shipped that branch cannot run (`tensor.shape(c, t*v, h, w)` at ours.py:1962 / 1975 calls a torch.Size); built
+    here is what it spells out: [T,C,V,h,w] -> [1,C,T*V,h,w] -> block -> back.  In channels-last terms the stacked
+    [T,V,h,w,C] tensor is already in that order, so it is a view; the re-associated dot attention makes the long axis
+    free (M = phi^T g / L is still [Ci,Ci]; BatchNorm3d / LayerNorm see the same rows as before)."""
+
+    def forward(self, x: Dict[str, torch.Tensor], is_video: bool = False):
+        self._is_video = bool(is_video)
+        try:
+            return super().forward(x)
+        finally:
+            self._is_video = False
+
+    def _attend(self, block, stacked):
+        if not getattr(self, "_is_video", False):
+            return block.forward_nvhwc(stacked)
+        t, v, h, w, c = stacked.shape
+        return block.forward_nvhwc(stacked.reshape(1, t * v, h, w, c)).reshape(t, v, h, w, c)
 
 
 class Global_and_Local_conv_merge(Global_and_Local):

@@ -279,6 +279,9 @@ class Global_and_Local(nn.Module):
                 for v in self.view_num}
         return mask, f4
 
+    def attend(self, block, stacked):
+        return block(stacked)[0]
+
     def fuse(self, v, g, l):
         return g + l                                                               # ours.py:1833-1834
 
@@ -295,8 +298,8 @@ class Global_and_Local(nn.Module):
             c = torch.sigmoid(self.centerness[v](f4[v]))                           # ours.py:1809-1811
             a = torch.sigmoid(self.center_aware_weight * m * c)                    # ours.py:1814-1815
             f4_local[v] = f4[v] * a                                                # ours.py:1816
-        g_out, _ = self.global_attn(torch.stack([f4[v] for v in self.view_num], dim=2))        # ours.py:1819-1821
-        l_out, _ = self.local_attn(torch.stack([f4_local[v] for v in self.view_num], dim=2))   # ours.py:1826-1828
+        g_out = self.attend(self.global_attn, torch.stack([f4[v] for v in self.view_num], dim=2))        # ours.py:1819-1821
+        l_out = self.attend(self.local_attn, torch.stack([f4_local[v] for v in self.view_num], dim=2))   # ours.py:1826-1828
         f4_g = {v: g_out[:, :, i] for i, v in enumerate(self.view_num)}
         f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
         mask, mask_bb = {}, {}
@@ -314,6 +317,27 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
         f4 = self.encode(x)
         mask, mask_bb, _, f4_l = self._forward_from_f4(x, f4)
         return mask, mask_bb, f4, f4_l
+
+
+class Global_and_Local_Temporal(Global_and_Local):
+    """ours.py:1846-1997 with the is_video branch as it is spelled out ([T,C,V,h,w] -> [1,C,T*V,h,w]; the shipped code
+    calls `tensor.shape(...)` there, ours.py:1962, and raises).  No reference fixture can exist for is_video=True; for
+    is_video=False it is Global_and_Local."""
+
+    def forward(self, x, is_video: bool = False):
+        self._video = bool(is_video)
+        try:
+            return self._forward_from_f4(x, self.encode(x))
+        finally:
+            self._video = False
+
+    def attend(self, block, stacked):                                              # stacked [T,C,V,h,w]
+        if not getattr(self, "_video", False):
+            return block(stacked)[0]
+        t, c, v, h, w = stacked.shape
+        folded = stacked.permute(1, 0, 2, 3, 4).reshape(c, t * v, h, w).unsqueeze(0)            # ours.py:1960-1962
+        out = block(folded)[0]
+        return out.squeeze(0).reshape(c, t, v, h, w).permute(1, 0, 2, 3, 4)                     # ours.py:1965
 
 
 class Global_and_Local_conv_merge(Global_and_Local):

@@ -371,3 +371,48 @@ def test_variants_train_step_vs_oracle(name):
     for k, p in model.named_parameters():
         if k.startswith(attn) and k in gref:
             assert float((p.grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm()) + 1e-3 * top, k
+
+
+def test_temporal_variant_vs_oracle():
+    """Global_and_Local_Temporal (ours.py:1846-1997): is_video folds the clip's frames into the attention axis.  The
+    shipped branch raises (torch.Size called, ours.py:1962), so the checker is the oracle's spelled-out version;
+    is_video=False must equal Global_and_Local."""
+    import glfusion_amd.models as M
+    from glfusion_amd import ops as _ops
+    _ops.set_precision("f16x3")                               # the bench default; one precision keeps the CPU oracle's share short
+    views, n = ["1", "3"], 3
+    ref = orc.Global_and_Local_Temporal(views)
+    orc.closed_form_fill(ref, salt=8)
+    ref.eval()
+    model = M.Global_and_Local_Temporal(views)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model = model.to(DEV).eval()
+    imgs = orc.closed_form_images(views, n, 112, 112)
+    dimgs = {v: t.to(DEV) for v, t in imgs.items()}
+    with torch.no_grad():
+        want_v, want_f = ref(imgs, True), ref(imgs, False)
+        got_v, got_f = model(dimgs, is_video=True), model(dimgs, is_video=False)
+    for want, got in ((want_v, got_v), (want_f, got_f)):
+        for v in views:
+            assert close(got[0][v], want[0][v]), v
+            assert close(got[1][v], want[1][v]), v
+            assert close(got[2][v], want[2][v], 1e-3), v
+            assert close(got[3][v], want[3][v], 1e-3), v
+    assert not close(got_v[0]["1"], got_f[0]["1"])            # folding time in changes the result
+    # training: gradients flow through the folded attention
+    model.train()
+    ref.train()
+    orc.set_dropout(model, 0.0)
+    orc.set_dropout(ref, 0.0)
+    from glfusion_amd import ops
+    tgts = orc.closed_form_targets(views, n)
+    lw = sum(torch.nn.functional.binary_cross_entropy_with_logits(ref(imgs, True)[0][v], tgts[v], reduction="sum") for v in views)
+    lw.backward()
+    pred = model(dimgs, is_video=True)[0]
+    lg = sum(ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
+    lg.backward()
+    assert abs(float(lg) - float(lw)) <= 2e-5 * abs(float(lw))
+    gw = ref.global_attn.g.weight.grad.double()
+    gg = model.global_attn.g.weight.grad.double().cpu()
+    _ops.set_precision("f32")
+    assert float((gg - gw).norm()) <= 3e-2 * float(gw.norm())          # fp32 gradient noise of this network: see test_gpu_engine
