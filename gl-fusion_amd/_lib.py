@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(ROOT, "include", "glfusion.h")
-LIB_PATH = os.path.join(_PKG, "lib", "libglfusion_hip.so")
+LIB_PATH = os.environ.get("GLF_LIB_PATH") or os.path.join(_PKG, "lib", "libglfusion_hip.so")   # override: A/B of two builds
 
 
 class GemmParams(C.Structure):
