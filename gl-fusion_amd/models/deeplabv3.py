@@ -7,6 +7,7 @@ taps that fall into the zero padding for a whole tile are skipped inside the con
 broadcast."""
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -15,6 +16,8 @@ from torch import nn
 from .. import ops
 from .layers import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, Dropout, ReLU, conv_bn_act
 from ._utils import _SimpleSegmentationModel_iekd
+
+_CAT_BUFFER = os.environ.get("GLF_ASPP_CAT", "1") != "0"
 
 __all__ = ["DeepLabV3_iekd", "DeepLabHead", "ASPP", "ASPPConv", "ASPPPooling"]
 
@@ -74,7 +77,20 @@ class ASPP(nn.Module):
     def trunk_nhwc(self, x):
         """Everything up to (not including) the Dropout: branches, projection, BN, ReLU."""
         xs = ops.fan_out(x, len(self.convs))              # one-pass gradient fan-in over the five branches
-        branches = [conv.forward_nhwc(xi) for conv, xi in zip(self.convs, xs)]
+        # every branch's last kernel (BatchNorm apply / broadcast) writes its 256 columns of ONE [N,h,w,1280] buffer, so
+        # the 1280 -> 256 projection is a single K = 1280 contraction (and one dgrad, one wgrad) -- still no concat copy
+        n, h, w = x.shape[0], x.shape[1], x.shape[2]
+        widths = [conv[0].out_channels if not isinstance(conv, ASPPPooling) else conv[1].out_channels for conv in self.convs]
+        cat = torch.empty(n, h, w, sum(widths), dtype=torch.float32, device=x.device)
+        slot = ops.amax_slot(x.device)
+        branches, off = [], 0
+        for conv, xi, ck in zip(self.convs, xs, widths):
+            if _CAT_BUFFER:
+                with ops.output_into(cat[..., off:off + ck], slot):
+                    branches.append(conv.forward_nhwc(xi))
+            else:
+                branches.append(conv.forward_nhwc(xi))
+            off += ck
         y = ops.conv1x1_cat(self.project[0].weight, branches)
         return self.project[1].forward_nhwc(y, relu=True)
 

@@ -469,10 +469,27 @@ class ConvCatFn(Function):
     @staticmethod
     def forward(ctx, weight, bias, *xs):
         _chk(weight, "weight")
-        xs = [_contig(_chk(t, "input")) for t in xs]
         cout, ctot = weight.shape[0], weight.shape[1]
         w2 = _contig(weight.detach()).view(cout, ctot)
         rows = xs[0].numel() // xs[0].shape[-1]
+        # inputs that ARE the column slices of one [..., ctot] buffer (ops.output_into): one K = ctot contraction
+        t0 = _chk(xs[0], "input")
+        offs = [0]
+        for t in xs:
+            offs.append(offs[-1] + t.shape[-1])
+        ctx.cat = (offs[-1] == ctot and not t0.is_contiguous() and t0.stride(-1) == 1 and t0.stride(-2) == ctot
+                   and all(_chk(t, "input").stride() == t0.stride() and t.shape[:-1] == t0.shape[:-1]
+                           and t.data_ptr() == t0.data_ptr() + 4 * o for t, o in zip(xs, offs)))
+        if ctx.cat:
+            y = torch.empty(*t0.shape[:-1], cout, dtype=torch.float32, device=t0.device)
+            gemm("nt", t0, w2, y, M=rows, N=cout, K=ctot, lda=ctot, ldb=ctot, ldc=cout, bias=bias,
+                 amax_a=amax_of(t0), amax_b=amax_of(weight))
+            ctx.save_for_backward(w2, *xs)
+            ctx.wshape = tuple(weight.shape)
+            ctx.weight_ref = weight
+            ctx.has_bias = bias is not None
+            return y
+        xs = [_contig(_chk(t, "input")) for t in xs]
         y = torch.empty(*xs[0].shape[:-1], cout, dtype=torch.float32, device=xs[0].device)
         off = 0
         for i, t in enumerate(xs):
@@ -503,6 +520,31 @@ class ConvCatFn(Function):
         grads = []
         off = 0
         am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
+        if ctx.cat:
+            t0 = xs[0]
+            if any(ctx.needs_input_grad[2:]):
+                dcat = torch.empty(*t0.shape[:-1], ctot, dtype=torch.float32, device=dy.device)
+                am_dc = amax_slot(dy.device)
+                if split_mode() and cout % 32 == 0:
+                    gemm("nt", dy, weight_T(w2, ctx.weight_ref), dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
+                         amax_a=am_dy, amax_b=am_w, amax_c=am_dc)
+                else:
+                    am_dc = None
+                    gemm("nn", dy, w2, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=ctot, ldc=ctot)
+                for t in xs:
+                    g = dcat[..., off:off + t.shape[-1]]
+                    set_amax(g, am_dc)
+                    grads.append(g)
+                    off += t.shape[-1]
+            else:
+                grads = [None] * len(xs)
+            if dw is not None:
+                split = _tn_split(rows, cout, ctot, 1)
+                if split > 1:
+                    dw.zero_()
+                gemm("tn", dy, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
+                     amax_a=am_dy, amax_b=amax_of(t0))
+            return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
         for i, t in enumerate(xs):
             ck = t.shape[-1]
             if ctx.needs_input_grad[2 + i]:
@@ -562,6 +604,52 @@ def stem7x7(x, weight, bias, pad: int):
 
 
 # ----------------------------------------------------------------------------------------
+# writing a branch's last kernel straight into a column slice of a wider buffer (ASPP: no concat, ONE projection GEMM)
+# ----------------------------------------------------------------------------------------
+_OUT_VIEW = [None]
+
+
+class output_into:
+    """Within the block, the next BatchNorm-apply / broadcast whose output has `view`'s shape writes into `view` (a
+    [..., C] column slice of a wider channels-last buffer: row stride = the buffer's channel count) instead of a
+    fresh tensor, and reports its maximum into `amax` (a slot shared by all writers of the buffer)."""
+
+    def __init__(self, view: torch.Tensor, amax: Optional[torch.Tensor] = None):
+        self.item = (view, amax)
+
+    def __enter__(self):
+        _OUT_VIEW[0] = self.item
+        return self
+
+    def __exit__(self, *exc):
+        _OUT_VIEW[0] = None
+        return False
+
+
+def _take_out(shape, device):
+    """(output tensor, row stride, shared amax slot or None) for a [..., C] result of `shape`."""
+    item = _OUT_VIEW[0]
+    if item is not None and tuple(item[0].shape) == tuple(shape) and item[0].stride(-1) == 1:
+        _OUT_VIEW[0] = None
+        return item[0], int(item[0].stride(-2)), item[1]
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device), int(shape[-1]), None
+
+
+def _rows_view(t: torch.Tensor):
+    """(tensor, row stride) for reading a [..., C] tensor as rows: contiguous, or a column slice of a wider
+    channels-last buffer (uniform row stride); anything else is copied."""
+    if t.is_contiguous():
+        return t, int(t.shape[-1])
+    if t.dim() >= 2 and t.stride(-1) == 1:
+        ld = int(t.stride(-2))
+        ok = all(t.stride(d) == t.stride(d + 1) * t.shape[d + 1] for d in range(t.dim() - 2))
+        if ok and ld >= t.shape[-1]:
+            return t, ld
+    t = t.contiguous()
+    return t, int(t.shape[-1])
+
+
+# ----------------------------------------------------------------------------------------
 # BatchNorm (+ residual, + ReLU)
 # ----------------------------------------------------------------------------------------
 _last_bn = [None]          # (mean, invstd, rows) of the most recent BatchNormActFn.forward (read by BN_TAP)
@@ -590,14 +678,14 @@ class BatchNormActFn(Function):
             check(lib.glf_bn_eval_coeffs(_p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
         if residual is not None:
             residual = _contig(_chk(residual, "bn residual"))
-        y = torch.empty_like(x)
-        am = amax_slot(dev)
-        check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
+        y, ldy, shared = _take_out(x.shape, dev)
+        am = shared if shared is not None else amax_slot(dev)
+        check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
                                int(relu), _p(am), _stream()), "bn_apply")
         set_amax(y, am)
         # without a residual the ReLU mask is recomputed from x in backward (sign of the same expression): y is not kept
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, gamma, beta if relu else None)
-        ctx.cfg = (rows, c, relu, training, residual is not None)
+        ctx.cfg = (rows, c, relu, training, residual is not None, ldy)
         _last_bn[0] = (mean, invstd, rows)
         return y
 
@@ -605,15 +693,15 @@ class BatchNormActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
-        rows, c, relu, training, has_res = ctx.cfg
-        dy = _contig(dy)
+        rows, c, relu, training, has_res, ldy = ctx.cfg
+        dy, lddy = _rows_view(dy)                 # may be a column slice of the concat-free projection's gradient
         dev = dy.device
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         am = amax_slot(dev)
-        check(lib.glf_bn_bwd(_p(dy), c, _p(x), c, _p(y), c, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
+        check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
                              _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), _stream()), "bn_bwd")
         set_amax(dx, am)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
@@ -774,8 +862,13 @@ class BroadcastFn(Function):
     def forward(ctx, x, h: int, w: int):
         x = _contig(_chk(x, "broadcast input"))
         n, c = x.shape[0], x.shape[-1]
-        y = torch.empty(n, h, w, c, dtype=torch.float32, device=x.device)
-        check(lib.glf_bcast_rows_fwd(_p(x), _p(y), c, n, h * w, c, _stream()), "bcast_rows")
+        y, ldy, shared = _take_out((n, h, w, c), x.device)
+        check(lib.glf_bcast_rows_fwd(_p(x), _p(y), ldy, n, h * w, c, _stream()), "bcast_rows")
+        if shared is not None:                   # the broadcast repeats x: its maximum is the source's
+            src = amax_of(x)
+            if src is not None:
+                torch.maximum(shared, src, out=shared)
+            set_amax(y, shared)
         ctx.cfg = (n, h, w, c)
         return y
 
@@ -783,9 +876,9 @@ class BroadcastFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         n, h, w, c = ctx.cfg
-        dy = _contig(dy)
+        dy, lddy = _rows_view(dy)
         dx = torch.empty(n, 1, 1, c, dtype=torch.float32, device=dy.device)
-        check(lib.glf_sum_rows_fwd(_p(dy), c, _p(dx), 1.0, n, h * w, c, _stream()), "bcast_rows_bwd")
+        check(lib.glf_sum_rows_fwd(_p(dy), lddy, _p(dx), 1.0, n, h * w, c, _stream()), "bcast_rows_bwd")
         return dx, None, None
 
 
