@@ -204,6 +204,7 @@ def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
 
 
 _TN_TARGET = int(os.environ.get("GLF_TN_TARGET", "0"))      # 0: per precision (below)
+_TN_ROUND = os.environ.get("GLF_TN_ROUND", "1") != "0"
 
 
 def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
@@ -215,7 +216,19 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     target = _TN_TARGET or (1024 if int(lib.glf_get_precision()) == 2 else 2048)
     want = max(1, (target + tiles - 1) // tiles)
     cap = max(1, rows // 512)
-    return int(max(1, min(want, cap, 65535 // max(batch, 1))))
+    hi = 65535 // max(batch, 1)
+    if _TN_ROUND and int(lib.glf_get_precision()) == 2:
+        # among the slice counts around the target, the one whose workgroups (256-wide tiles, one per CU) fill whole
+        # rounds of the 256 CUs best
+        wg = ((m + 255) // 256) * ((n + 127) // 128) * max(ntaps, 1) * batch
+        best, best_score = want, -1.0
+        for s in range(max(1, want // 2), max(1, min(want * 2, cap, hi)) + 1):
+            b = wg * s
+            score = b / (((b + 255) // 256) * 256.0) - 0.004 * s
+            if score > best_score:
+                best, best_score = s, score
+        want = best
+    return int(max(1, min(want, cap, hi)))
 
 
 def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
