@@ -224,6 +224,7 @@ class Global_only(_PerViewNetworks):
     """Ablation without the local branch (ours.py:1999-2111): mask = classifier(global fusion), mask_bb =
     classifier(f4); the centerness heads exist (state_dict) but are not evaluated.  Returns
     (mask, mask_bb, f4_global_fusion, None)."""
+    _third_output_is_f4 = False
 
     def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
         super().__init__(view_num, test_view, center_aware_weight)
@@ -235,7 +236,7 @@ class Global_only(_PerViewNetworks):
         ho, wo = int(hw[0]), int(hw[1])
 
         def view_section(v):                                 # ours.py:2085-2090
-            return ops.fan_out(self._encode_view(v, x[v]), 2)             # global fusion / mask_bb
+            return ops.fan_out(self._encode_view(v, x[v]), 3 if self._third_output_is_f4 else 2)   # global fusion / mask_bb (/ raw f4)
 
         secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
         g_out = self.global_attn.forward_nvhwc(ops.stack_views([s[0] for s in secs]))            # ours.py:2093-2097
@@ -252,7 +253,19 @@ class Global_only(_PerViewNetworks):
             f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)
             f4_g[v]._glf_stack = (g_out, i)
             mask[v], mask_bb[v] = heads[i]
+        if self._third_output_is_f4:                                   # Global_only_cyc_nofusion (ours.py:3139)
+            return mask, mask_bb, {v: ops.from_nhwc(s[2]) for v, s in zip(views, secs)}, None
         return mask, mask_bb, f4_g, None
+
+
+class Global_only_cyc_nofusion(Global_only):
+    """ours.py:3026-3139: Global_only returning the un-fused layer4 features as third output: (mask, mask_bb, f4, None).
+    Its constructor registers BOTH fusion blocks (ours.py:3065-3066): `local_attn.*` is in the state_dict, unused."""
+    _third_output_is_f4 = True
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__(view_num, test_view, center_aware_weight)
+        self.local_attn = TPAVIModule(in_channels=2048, mode="dot")
 
 
 class Local_only(_PerViewNetworks):

@@ -373,6 +373,21 @@ class Global_only(Global_and_Local):
         return mask, mask_bb, f4_g, None
 
 
+class Global_only_cyc_nofusion(Global_and_Local):
+    """ours.py:3026-3139: Global_only's forward returning (mask, mask_bb, f4, None); its constructor still registers
+    BOTH fusion blocks (ours.py:3065-3066), so `local_attn.*` is in the state_dict and never used."""
+
+    def forward(self, x):
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = self.encode(x)
+        g_out, _ = self.global_attn(torch.stack([f4[v] for v in self.view_num], dim=2))
+        mask, mask_bb = {}, {}
+        for i, v in enumerate(self.view_num):
+            mask[v] = F.interpolate(self.classifier[v](g_out[:, :, i].contiguous()), size=hw, mode="bilinear", align_corners=False)
+            mask_bb[v] = F.interpolate(self.classifier[v](f4[v]), size=hw, mode="bilinear", align_corners=False)
+        return mask, mask_bb, f4, None
+
+
 class Local_only(Global_and_Local):
     """ours.py:2113-2249: no global branch; returns (mask, mask_bb, atten_map, local fusion features)."""
 
