@@ -303,6 +303,11 @@ def main():
                                  "per_kernel_s_per_step": {k: round(a[0] / psteps, 4) for k, a in sorted(agg.items())}},
             "whole_step_dense_tflops": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
         }
+        if split:
+            # profiles/r01_mfma_peak_microbench.txt: back-to-back 16-bit MFMAs with no memory traffic reach 2.47 PF on constant
+            # operands but 1.42-1.57 PF (fp16) on random ones -- on real data the matrix cores are power-limited
+            roofline["power_limited_peak_measured"] = {"value": 1500.0, "unit": "TFLOP/s", "frac": round(achieved / 1500.0, 4),
+                                                       "source": "scratch/ubench/mfma_peak.hip, random operands"}
         if prof_iso:
             tsecs, tdense, tkept, tlaunch = agg_timed[name]
             roofline["measured"] = (f"HIP events around every launch, {iso_steps} step(s) on ONE stream right after the timed region: "
