@@ -113,8 +113,8 @@ def cpu_baseline(frames_per_view: int = 4, steps: int = 2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
