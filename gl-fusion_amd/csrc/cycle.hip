@@ -151,7 +151,31 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x,
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = x[i] * k;
 }
 
+// out = a * x + b * y
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                                    float a, float b, long long n4, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i], yv = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z, a * xv.w + b * yv.w);
+    }
+    for (long long i = 4 * n4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
 }  // namespace
+
+extern "C" int glf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t numel, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && y && out, GLF_ERR_NULL, "axpby: null argument");
+    GLF_REQUIRE(numel > 0, GLF_ERR_BAD_SHAPE, "axpby: numel must be > 0");
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    const long long n4 = vec ? numel / 4 : 0;
+    long long blocks = (numel / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, glf::S(s), x, y, out, a, b, n4, (long long)numel);
+    return glf::check_launch("axpby");
+}
 
 extern "C" int glf_seg_cycle(const float* feat, int T, int F, int target_region, int cyc_off, int chunk_size, float temperature,
                              int start0, int n_starts, int stride, float weight, int soft_label, float* loss_out, float* dfeat,

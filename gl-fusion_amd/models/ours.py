@@ -113,6 +113,7 @@ class _PerViewNetworks(nn.Module):
 class Global_and_Local(_PerViewNetworks):
     """ours.py:1708-1843."""
     _third_output_is_f4 = False
+    _global_gets_background = False
 
     def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
         super().__init__(view_num, test_view, center_aware_weight)
@@ -140,7 +141,11 @@ class Global_and_Local(_PerViewNetworks):
             fa, fb, fc, fg, *raw = ops.fan_out(f, 5 if self._third_output_is_f4 else 4)   # classifier / centerness / gate / global fusion
             cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
             ctr = self.centerness[v].forward_nhwc(fb)
-            return again, fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight), (raw[0] if raw else None)
+            gated = ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+            if self._global_gets_background:                            # Foreground_and_Background (ours.py:2966)
+                g1, g2 = ops.fan_out(gated, 2)
+                fg, gated = ops.axpby(fg, g1, 1.0, -1.0), g2            # f4 * (1 - a) = f4 - f4 * a
+            return again, fg, gated, (raw[0] if raw else None)
 
         secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
         cls_again = {v: s[0] for v, s in zip(views, secs)}
@@ -174,6 +179,19 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
     """ours.py:2628-2764: the same network; returns the un-fused layer4 features as third output (the cycle loss of that
     experiment is taken on them): (mask, mask_bb, f4, f4_local_fusion)."""
     _third_output_is_f4 = True
+
+
+class Foreground_and_Background(Global_and_Local):
+    """ours.py:2887-3024: the gate splits f4 into foreground f4*a (local fusion block) and background f4*(1-a) (global
+    fusion block, instead of the un-gated f4); returns (mask, mask_bb, f4_fusion, None) with f4_fusion = the sum of the
+    two blocks' outputs."""
+    _global_gets_background = True
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        mask, mask_bb, f4_g, f4_l = super().forward(x)
+        g_out, l_out = f4_g[self.view_num[0]]._glf_stack[0], f4_l[self.view_num[0]]._glf_stack[0]
+        fused = ops.add_views(g_out, l_out)                              # ours.py:3013-3014 (returned as features)
+        return mask, mask_bb, {v: ops.from_nhwc(fused[i]) for i, v in enumerate(self.view_num)}, None
 
 
 class Global_and_Local_Temporal(Global_and_Local):

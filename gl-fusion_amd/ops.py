@@ -1045,6 +1045,39 @@ def local_gate(cls_logits, ctr_logits, f4, weight: float):
     return GateFn.apply(cls_logits, ctr_logits, f4, float(weight))
 
 
+class AxpbyFn(Function):
+    """out = a*x + b*y on tensors of one shape."""
+
+    @staticmethod
+    def forward(ctx, x, y, a: float, b: float):
+        x, y = _contig(_chk(x, "x")), _contig(_chk(y, "y"))
+        if x.shape != y.shape:
+            raise RuntimeError("axpby: shapes differ")
+        out = torch.empty_like(x)
+        check(lib.glf_axpby(_p(x), _p(y), _p(out), a, b, x.numel(), _stream()), "axpby")
+        ctx.ab = (a, b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        a, b = ctx.ab
+        d = _contig(d)
+        zero = d                                   # a*d + 0*d
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(d)
+            check(lib.glf_axpby(_p(d), _p(zero), _p(dx), a, 0.0, d.numel(), _stream()), "axpby_bwd")
+        if ctx.needs_input_grad[1]:
+            dy = torch.empty_like(d)
+            check(lib.glf_axpby(_p(d), _p(zero), _p(dy), b, 0.0, d.numel(), _stream()), "axpby_bwd")
+        return dx, dy, None, None
+
+
+def axpby(x, y, a: float, b: float):
+    return AxpbyFn.apply(x, y, float(a), float(b))
+
+
 class GateMapFn(GateFn):
     """GateFn that also hands out the gate map a = sigmoid(w * max_c sigmoid(cls) * sigmoid(ctr)) as [N,1,h,w]
     (Local_only returns it as `atten_map`, ours.py:2221-2222, 2249); the map is a non-differentiable output."""

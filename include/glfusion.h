@@ -288,6 +288,9 @@ int glf_adam_step(const int64_t* table, int n_rows, double lr, double beta1, dou
 int glf_seg_cycle(const float* feat, int T, int F, int target_region, int cyc_off, int chunk_size, float temperature,
                   int start0, int n_starts, int stride, float weight, int soft_label, float* loss_out, float* dfeat,
                   glf_stream_t s);
+/* out = a*x + b*y (out may alias x or y): the background branch f4 * (1 - gate) = f4 - f4 * gate of
+ * Foreground_and_Background (ours.py:2966) and its gradient. */
+int glf_axpby(const float* x, const float* y, float* out, float a, float b, int64_t numel, glf_stream_t s);
 /* y = x * scale * (*scale_dev) (scale_dev: device scalar, may be NULL): a saved gradient times autograd's
  * upstream gradient. */
 int glf_scale(const float* x, float* y, int64_t numel, float scale, const float* scale_dev, glf_stream_t s);

@@ -290,7 +290,7 @@ class Global_and_Local(nn.Module):
 
     def _forward_from_f4(self, x, f4):
         hw = x[self.view_num[0]].shape[-2:]
-        f4_local = {}
+        f4_local, f4_bg = {}, {}
         for v in self.view_num:
             # ours.py:1802-1807: AdaptiveMaxPool3d((1,h,w)) on a 4-D tensor == max over the class channels
             s = torch.sigmoid(self.classifier[v](f4[v]))
@@ -298,7 +298,10 @@ class Global_and_Local(nn.Module):
             c = torch.sigmoid(self.centerness[v](f4[v]))                           # ours.py:1809-1811
             a = torch.sigmoid(self.center_aware_weight * m * c)                    # ours.py:1814-1815
             f4_local[v] = f4[v] * a                                                # ours.py:1816
-        g_out = self.attend(self.global_attn, torch.stack([f4[v] for v in self.view_num], dim=2))        # ours.py:1819-1821
+            if getattr(self, "global_on_background", False):
+                f4_bg[v] = f4[v] * (torch.ones_like(a) - a)                        # ours.py:2966
+        g_in = f4_bg if f4_bg else f4
+        g_out = self.attend(self.global_attn, torch.stack([g_in[v] for v in self.view_num], dim=2))      # ours.py:1819-1821
         l_out = self.attend(self.local_attn, torch.stack([f4_local[v] for v in self.view_num], dim=2))   # ours.py:1826-1828
         f4_g = {v: g_out[:, :, i] for i, v in enumerate(self.view_num)}
         f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
@@ -317,6 +320,15 @@ class Global_and_Local_cyc_nofusion(Global_and_Local):
         f4 = self.encode(x)
         mask, mask_bb, _, f4_l = self._forward_from_f4(x, f4)
         return mask, mask_bb, f4, f4_l
+
+
+class Foreground_and_Background(Global_and_Local):
+    """ours.py:2887-3024: global block on f4*(1-a), local block on f4*a; returns (mask, mask_bb, f4_fusion, None)."""
+    global_on_background = True
+
+    def forward(self, x):
+        mask, mask_bb, f4_g, f4_l = self._forward_from_f4(x, self.encode(x))
+        return mask, mask_bb, {v: f4_g[v] + f4_l[v] for v in self.view_num}, None
 
 
 class Global_and_Local_Temporal(Global_and_Local):

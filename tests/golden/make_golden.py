@@ -206,7 +206,7 @@ def variants_fixture(ours) -> None:
     """the two single-branch ablations, eval() outputs of the reference's own classes."""
     views, n = ["1", "3"], 2
     imgs = orc.closed_form_images(views, n, 112, 112)
-    for name in ("Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion"):
+    for name in ("Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background"):
         model = getattr(ours, name)(views)
         orc.closed_form_fill(model, salt=6)
         model.eval()

@@ -314,7 +314,7 @@ def _sample(t, k=4099):
     return flat[torch.from_numpy(idx).to(flat.device)]
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background"])
 def test_variants_eval_vs_golden(golden_dir, name, precision):
     """Global_only / Local_only (ours.py:1999-2249) against outputs of the reference's own classes."""
     import glfusion_amd.models as M
@@ -329,7 +329,7 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
     imgs = {v: t.to(DEV) for v, t in orc.closed_form_images(views, n, 112, 112).items()}
     with torch.no_grad():
         out = model(imgs)
-    assert (out[3] is None) == name.startswith("Global_only")
+    assert (out[3] is None) == (name.startswith("Global_only") or name == "Foreground_and_Background")
     for v in views:
         assert close(out[0][v], torch.from_numpy(g[f"mask:{v}"])), v
         assert close(out[1][v], torch.from_numpy(g[f"mask_bb:{v}"])), v
@@ -342,7 +342,7 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
             assert close(_sample(third), torch.from_numpy(g[f"third:{v}"]), 1e-3), v
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge", "Foreground_and_Background"])
 def test_variants_train_step_vs_oracle(name):
     import glfusion_amd.models as M
     from glfusion_amd import ops
