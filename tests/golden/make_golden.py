@@ -214,8 +214,10 @@ def variants_fixture(ours) -> None:
             out = model(imgs)
         d = {"keys": np.array(list(model.state_dict().keys()))}
         for v in views:
-            d[f"mask:{v}"] = t2n(out[0][v])
-            d[f"mask_bb:{v}"] = t2n(out[1][v])
+            # a 20 011-point strided sample of each logit map (full maps for every variant would be 13 MB of fixtures)
+            idx = torch.from_numpy(sample_idx(out[0][v].numel(), 20011))
+            d[f"mask:{v}"] = t2n(out[0][v].reshape(-1)[idx])
+            d[f"mask_bb:{v}"] = t2n(out[1][v].reshape(-1)[idx])
             third = out[2][v]
             d[f"third:{v}"] = t2n(third) if third.shape[1] == 1 else t2n(third.reshape(-1)[torch.from_numpy(sample_idx(third.numel(), 4099))])
             if out[3] is not None:

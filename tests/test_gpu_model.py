@@ -331,8 +331,9 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
         out = model(imgs)
     assert (out[3] is None) == (name.startswith("Global_only") or name == "Foreground_and_Background")
     for v in views:
-        assert close(out[0][v], torch.from_numpy(g[f"mask:{v}"])), v
-        assert close(out[1][v], torch.from_numpy(g[f"mask_bb:{v}"])), v
+        assert tuple(out[0][v].shape) == (n, 5, 112, 112) and tuple(out[1][v].shape) == (n, 5, 112, 112)
+        assert close(_sample(out[0][v], 20011), torch.from_numpy(g[f"mask:{v}"])), v
+        assert close(_sample(out[1][v], 20011), torch.from_numpy(g[f"mask_bb:{v}"])), v
         third = out[2][v]
         if name == "Local_only":
             assert tuple(third.shape) == (n, 1, 28, 28)

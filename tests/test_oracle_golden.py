@@ -167,4 +167,7 @@ def test_oracle_variants_match_reference_fixture(golden_dir, name):
     for v in views:
         for slot, key in ((0, "mask"), (1, "mask_bb")):
             ref = torch.from_numpy(g[f"{key}:{v}"])
-            assert float((out[slot][v] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (key, v)
+            flat = out[slot][v].reshape(-1)
+            idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(20011, flat.numel())).astype(np.int64))
+            got = flat[torch.from_numpy(idx)]
+            assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (key, v)
