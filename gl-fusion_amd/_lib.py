@@ -32,6 +32,7 @@ class GemmParams(C.Structure):
         ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32), ("rect", C.c_int32),
         ("amax_a", C.c_void_p), ("amax_b", C.c_void_p), ("amax_c", C.c_void_p),
         ("colstats", C.c_void_p),
+        ("precision", C.c_int32),
     ]
 
 

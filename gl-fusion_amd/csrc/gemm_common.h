@@ -36,7 +36,7 @@ int init_gemm_f16s_attrs();                    // gemm_f16s.hip
 int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s);
-float* amax_scratch(int n);                    // n consecutive device floats from a ring (glf_api.hip)
+float* amax_scratch(int n, hipStream_t s);     // n consecutive device floats from the ring of stream s (glf_api.hip)
 const float* zero_page();                      // ZERO_PAGE_FLOATS zeros on the device (glf_api.hip)
 bool f16s_rows_ok(const GemmArgs& a);
 bool f16s_tn_ok(const GemmArgs& a);
@@ -155,6 +155,7 @@ int validate(const glf_gemm_params* p, const void* A, const void* B, const void*
     GLF_REQUIRE(p->taps >= 1 && p->taps <= 32, GLF_ERR_BAD_SHAPE, "gemm: taps must be in [1,32] (got %d)", p->taps);
     GLF_REQUIRE(p->batch >= 1 && p->batch <= 65535, GLF_ERR_BAD_SHAPE, "gemm: batch out of range (%d)", p->batch);
     GLF_REQUIRE(p->gather >= 0 && p->gather <= 2, GLF_ERR_BAD_SHAPE, "gemm: gather must be 0,1,2");
+    GLF_REQUIRE(p->precision >= 0 && p->precision <= 3, GLF_ERR_UNSUPPORTED, "gemm: precision must be 0 (process default), 1 (fp32), 2 (bf16x6) or 3 (f16x3)");
     const unsigned full = p->taps == 32 ? 0xffffffffu : ((1u << p->taps) - 1u);
     GLF_REQUIRE((p->tap_mask & ~full) == 0, GLF_ERR_BAD_SHAPE, "gemm: tap_mask has bits beyond taps");
     if (p->gather) {
@@ -199,6 +200,11 @@ int setup_rect(const glf_gemm_params* p, const float* bias, GemmArgs& a, dim3& g
     a.rect = 1;
     grid = dim3((unsigned)(tiles * a.tiles_n), 1, 1);
     return GLF_OK;
+}
+
+// contraction precision of this call: glf_gemm_params.precision (1 + mode) or, when 0, the process default
+inline int call_precision(const glf_gemm_params* p) {
+    return (p->precision >= 1 && p->precision <= 3) ? p->precision - 1 : glf::precision();
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -600,7 +600,7 @@ namespace {
 // f16x3 with amax_a / amax_b == NULL: measure the operands (exactly the elements the call can read) first
 int self_amax(GemmArgs& a, const glf_gemm_params* p, bool tn, hipStream_t s) {
     if (a.amax_a && a.amax_b) return GLF_OK;
-    float* slots = glf::amax_scratch(2);
+    float* slots = glf::amax_scratch(2, s);
     GLF_REQUIRE(slots != nullptr, GLF_ERR_WORKSPACE, "gemm(f16x3): no amax scratch");
     hipError_t e = hipMemsetAsync(slots, 0, 2 * sizeof(float), s);
     if (e != hipSuccess) return glf::fail(GLF_ERR_LAUNCH, "hipMemsetAsync(amax): %s", hipGetErrorString(e));
@@ -646,11 +646,12 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
                                "gemm_nt: M (%d) != n_img*hd*wd", p->M);
     if (p->tap_mask == 0) return glf::fail(GLF_ERR_BAD_SHAPE, "gemm_nt: empty tap_mask");
     GemmArgs a = make_args(A, B, bias, C, p);
+    const int prec = call_precision(p);
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
     if (p->rect == 2) {                 // region mode: f16x3 kernels only (see region_of in gemm_common.h)
-        GLF_REQUIRE(glf::precision() == 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
+        GLF_REQUIRE(prec == 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
                     "glf_gemm_nt: rect = 2 (region mode) exists on the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands)");
         GLF_REQUIRE(p->gather != 0 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad == p->dil && p->hs == p->hd && p->ws == p->wd &&
                     p->batch == 1, GLF_ERR_UNSUPPORTED, "glf_gemm_nt: region mode needs a 3x3 stride-1 conv with pad == dil on equal maps, batch 1");
@@ -658,10 +659,10 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     } else if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
-    GLF_REQUIRE(!p->colstats || (glf::precision() == 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
+    GLF_REQUIRE(!p->colstats || (prec == 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
                 "glf_gemm_nt: colstats is honoured by the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands, no rect = 1, batch 1)");
-    if (glf::precision() == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
-    if (glf::precision() == 2 && glf::f16s_rows_ok(a)) {
+    if (prec == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
+    if (prec == 2 && glf::f16s_rows_ok(a)) {
         if (int rc = self_amax(a, p, false, glf::S(stream))) return rc;
         return glf::launch_rows_f16s(a, grid, p->gather != 0, glf::S(stream));
     }
@@ -715,8 +716,9 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
         a.rect = 1;
     }
     dim3 grid(a.tiles_m * a.tiles_n, ntap, p->batch * a.split);
-    if (glf::precision() == 1 && glf::bf16s_tn_ok(a)) return glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
-    if (glf::precision() == 2 && glf::f16s_tn_ok(a)) {
+    const int prec = call_precision(p);
+    if (prec == 1 && glf::bf16s_tn_ok(a)) return glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
+    if (prec == 2 && glf::f16s_tn_ok(a)) {
         if (int rc = self_amax(a, p, true, glf::S(stream))) return rc;
         return glf::launch_tn_f16s(a, grid, p->gather != 0, glf::S(stream));
     }

@@ -2,6 +2,7 @@
 #include "gemm_common.h"
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 namespace glf {
 
@@ -20,52 +21,84 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static std::atomic<int> g_cus{0};
 static std::atomic<int> g_precision{0};
 
 int precision() { return g_precision.load(std::memory_order_relaxed); }
-static std::once_flag g_once;
-static int g_init_rc = GLF_OK;
 
-// ring of device floats for operand maxima the library measures itself (f16x3 with amax_a/amax_b == NULL).
-// A slot is written (memset + amax kernel) and read (GEMM) on one stream in order; it is reused RING calls later.
-static float* g_ring = nullptr;
-static float* g_zeros = nullptr;
-const float* zero_page() { return g_zeros; }
-static std::atomic<unsigned> g_ring_pos{0};
-constexpr unsigned RING = 1u << 14;
-float* amax_scratch(int n) {
-    if (!g_ring) return nullptr;
-    const unsigned p = g_ring_pos.fetch_add((unsigned)n, std::memory_order_relaxed);
-    unsigned i = p % RING;
-    if (i + (unsigned)n > RING) i = 0;
-    return g_ring + i;
+// Library-owned device memory (the ONLY allocations the library makes; include/glfusion.h documents them):
+//   * one zero page of ZERO_PAGE_FLOATS floats per device (f16x3 kernels load padding / overhang rows from it),
+//   * one ring of RING floats per (device, stream) for operand maxima the library measures itself (f16x3 with
+//     amax_a / amax_b == NULL).  A slot is written (memset + amax kernel) and read (GEMM) on that one stream, in
+//     order, so reuse after the ring wraps is ordered by the stream itself.
+// Both are created lazily on first use on a device / stream and live until the process exits.
+constexpr unsigned RING = 1u << 12;
+struct StreamRing { float* base = nullptr; unsigned pos = 0; };
+struct DeviceState {
+    int cus = 0;
+    float* zeros = nullptr;
+    std::unordered_map<hipStream_t, StreamRing> rings;
+};
+static std::mutex g_mu;
+static std::unordered_map<int, DeviceState> g_dev;
+static thread_local int t_dev = -1;            // device the calling thread last initialised (fast path)
+static thread_local DeviceState* t_state = nullptr;
+
+static DeviceState* state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev == t_dev && t_state) return t_state;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dev.find(dev);
+    if (it == g_dev.end()) return nullptr;
+    t_dev = dev; t_state = &it->second;        // unordered_map nodes are address-stable
+    return t_state;
+}
+
+const float* zero_page() {
+    DeviceState* st = state();
+    return st ? st->zeros : nullptr;
+}
+
+float* amax_scratch(int n, hipStream_t s) {
+    DeviceState* st = state();
+    if (!st) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamRing& r = st->rings[s];
+    if (!r.base) {
+        if (hipMalloc(reinterpret_cast<void**>(&r.base), RING * sizeof(float)) != hipSuccess) { r.base = nullptr; return nullptr; }
+    }
+    if (r.pos + (unsigned)n > RING) r.pos = 0;
+    float* out = r.base + r.pos;
+    r.pos += (unsigned)n;
+    return out;
 }
 
 int num_cus() {
-    int v = g_cus.load(std::memory_order_relaxed);
-    return v > 0 ? v : 256;
+    DeviceState* st = state();
+    return (st && st->cus > 0) ? st->cus : 256;
 }
 
 int ensure_init() {
-    std::call_once(g_once, [] {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) { g_init_rc = fail(GLF_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e)); return; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev == t_dev && t_state) return GLF_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dev.find(dev);
+    if (it == g_dev.end()) {
+        DeviceState st;
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, dev);
-        if (e != hipSuccess) { g_init_rc = fail(GLF_ERR_LAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e)); return; }
-        g_cus.store(prop.multiProcessorCount);
-        g_init_rc = init_gemm_attrs();
-        if (g_init_rc == GLF_OK) {
-            e = hipMalloc(reinterpret_cast<void**>(&g_ring), RING * sizeof(float));
-            if (e != hipSuccess) { g_ring = nullptr; g_init_rc = fail(GLF_ERR_WORKSPACE, "hipMalloc(amax ring): %s", hipGetErrorString(e)); return; }
-            e = hipMalloc(reinterpret_cast<void**>(&g_zeros), ZERO_PAGE_FLOATS * sizeof(float));
-            if (e == hipSuccess) e = hipMemset(g_zeros, 0, ZERO_PAGE_FLOATS * sizeof(float));
-            if (e != hipSuccess) { g_zeros = nullptr; g_init_rc = fail(GLF_ERR_WORKSPACE, "hipMalloc(zero page): %s", hipGetErrorString(e)); }
-        }
-    });
-    return g_init_rc;
+        if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        st.cus = prop.multiProcessorCount;
+        if (int rc = init_gemm_attrs()) return rc;           // hipFuncSetAttribute is per device
+        e = hipMalloc(reinterpret_cast<void**>(&st.zeros), ZERO_PAGE_FLOATS * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(st.zeros, 0, ZERO_PAGE_FLOATS * sizeof(float));
+        if (e != hipSuccess) return fail(GLF_ERR_WORKSPACE, "hipMalloc(zero page): %s", hipGetErrorString(e));
+        it = g_dev.emplace(dev, std::move(st)).first;
+    }
+    t_dev = dev; t_state = &it->second;
+    return GLF_OK;
 }
 
 }  // namespace glf

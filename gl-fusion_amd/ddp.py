@@ -38,6 +38,7 @@ class _Bucket:
             self.offsets.append(off)
             off += p.numel()
         self.pending = len(params)
+        self.fired = [False] * len(params)   # whose post-accumulate hook ran this step
         self.work = None
         self.events = []        # one per gradient copied on a GPU stream (the model runs its views on side streams)
 
@@ -97,18 +98,22 @@ class GradAllReducer:
             e.record(torch.cuda.current_stream(b.flat.device))
             b.events.append(e)
         b.pending -= 1
+        b.fired[i] = True
         if b.pending == 0:
             self._launch(b)
 
     def finalize(self) -> None:
-        """Call once after backward(): launches buckets that did not fill (unused parameters contribute
-        zeros), waits for the collectives and re-points every .grad at its reduced bucket slice."""
+        """Call once after backward(): launches buckets that did not fill, waits for the collectives and re-points the
+        .grad of every parameter that RECEIVED a gradient this step at its reduced bucket slice.  A parameter whose hook
+        never fired (unused in this step's graph -- the same set on every rank, the graph being the same) contributes
+        zeros to the collective and keeps `.grad` as it was (None after zero_grad(set_to_none=True)): the optimizer
+        skips it exactly as it does on one GPU, so results do not depend on the world size."""
         if self.world == 1:
             return
         for b in self.buckets:
             if b.work is None:
-                for i, p in enumerate(b.params):           # parameters whose hook never fired this step
-                    if p.grad is None:
+                for i, p in enumerate(b.params):
+                    if not b.fired[i]:
                         off = b.offsets[i]
                         b.flat[off:off + p.numel()].zero_()
                 self._launch(b)
@@ -117,9 +122,11 @@ class GradAllReducer:
             if self.average:
                 b.flat.div_(self.world)
             for i, p in enumerate(b.params):
-                off = b.offsets[i]
-                p.grad = b.flat[off:off + p.numel()].view_as(p)
+                if b.fired[i]:
+                    off = b.offsets[i]
+                    p.grad = b.flat[off:off + p.numel()].view_as(p)
             b.pending = len(b.params)
+            b.fired = [False] * len(b.params)
             b.work = None
 
     def remove(self) -> None:

@@ -133,4 +133,4 @@ class Trainer:
         os.makedirs(d, exist_ok=True)
         torch.save({"network": self.model.state_dict()}, os.path.join(d, "net_%05d.pth" % epoch))
         with open(os.path.join(d, "latest.ckpt"), "w") as f:
-            f.write(str(epoch))
+            f.write("%05d" % epoch)                                # main.py:869: zero-padded, as the reference echoes it

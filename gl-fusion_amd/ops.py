@@ -104,6 +104,10 @@ def tap_mask(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, 
     return m
 
 
+# contraction precision of the calls this module issues (index into PRECISIONS); passed PER CALL through
+# glf_gemm_params.precision, so nothing process-wide is touched in the library
+_PREC = [0]
+
 # bench.py sets this to a list to time every contraction launch with HIP events on the launch stream
 PROFILER = None
 KERNEL_NAMES = {("nt", False): "gemm_rows_kernel<0,false>", ("nt", True): "gemm_rows_kernel<0,true>",
@@ -133,6 +137,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
+    p.precision = _PREC[0] + 1
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -160,7 +165,7 @@ def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     used).  Measured once per tensor and version and remembered on the tensor object; a permutation of the
     elements (weight re-layouts) has the same maximum, so callers pass the owning parameter.  Only call it on
     tensors whose contents are final (raw kernel writes do not bump torch's version counter)."""
-    if t is None or int(lib.glf_get_precision()) != 2:
+    if t is None or _PREC[0] != 2:
         return None
     hit = getattr(t, "_glf_amax", None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
@@ -186,7 +191,7 @@ def amax_slot(dev) -> Optional[torch.Tensor]:
     """A zeroed device float for a kernel that reports max|output| as a by-product (None unless f16x3 is
     active).  Slots come from a pre-zeroed pool per stream (one fill kernel per 4096 slots); a used-up pool stays
     alive through the slices that reference it."""
-    if int(lib.glf_get_precision()) != 2:
+    if _PREC[0] != 2:
         return None
     key = torch.cuda.current_stream().cuda_stream          # the fill kernel and the users must share a stream
     pool = _amax_pool.get(key)
@@ -213,11 +218,11 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     tiles = ((m + 127) // 128) * ((n + 127) // 128) * max(ntaps, 1) * batch
     # workgroups to aim for: 2048 128x128 tiles on the fp32 / bf16x6 kernels (two per CU); the f16x3 kernel has 256-wide
     # tiles, one workgroup per CU, and shares the chip with other streams: 1024 measured best (293.5 vs 299.2 ms / step)
-    target = _TN_TARGET or (1024 if int(lib.glf_get_precision()) == 2 else 2048)
+    target = _TN_TARGET or (1024 if _PREC[0] == 2 else 2048)
     want = max(1, (target + tiles - 1) // tiles)
     cap = max(1, rows // 512)
     hi = 65535 // max(batch, 1)
-    if _TN_ROUND and int(lib.glf_get_precision()) == 2:
+    if _TN_ROUND and _PREC[0] == 2:
         # among the slice counts around the target, the one whose workgroups (256-wide tiles, one per CU) fill whole
         # rounds of the 256 CUs best
         wg = ((m + 255) // 256) * ((n + 127) // 128) * max(ntaps, 1) * batch
@@ -247,7 +252,7 @@ def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
 
 def split_mode() -> bool:
     """True when contractions run on a split (bf16x6 / f16x3) kernel family, which has NT and TN forms only."""
-    return int(lib.glf_get_precision()) >= 1
+    return _PREC[0] >= 1
 
 
 def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.Tensor:
@@ -349,12 +354,12 @@ def region_mode(taps: int, kh: int, stride: int, pad: int, dil: int, h: int, w: 
     outputs, 392 workgroups) is faster as per-tap rectangles -- the regions' blocks are fewer and of uneven length
     (4 / 6 / 9 taps) -- and for dilations 1-4 the 5-18 % of padding work saved is less than the extra partial tiles
     and the per-element pixel arithmetic of the epilogue cost."""
-    return (os.environ.get("GLF_REGION", "1") != "0" and int(lib.glf_get_precision()) == 2 and taps == 9 and kh == 3 and stride == 1 and pad == dil and h == ho and w == wo
+    return (os.environ.get("GLF_REGION", "1") != "0" and _PREC[0] == 2 and taps == 9 and kh == 3 and stride == 1 and pad == dil and h == ho and w == wo
             and k % 32 == 0 and frac < RECT_THRESHOLD["region"])
 
 
 def _rect_thr(which: str) -> float:
-    if which == "dgrad" and int(lib.glf_get_precision()) == 2:
+    if which == "dgrad" and _PREC[0] == 2:
         return RECT_THRESHOLD["dgrad_f16x3"]
     return RECT_THRESHOLD[which]
 
@@ -458,7 +463,7 @@ def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1, co
 def conv_stats_fusable(weight, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
     """True when conv2d(..., colstats=) is honoured: f16x3 kernels (Cin % 32 == 0, Cout % 4 == 0) and the conv is not
     one that runs as per-tap rectangles with atomics (ASPP rate 12 / 24 forward)."""
-    if int(lib.glf_get_precision()) != 2:
+    if _PREC[0] != 2:
         return False
     cout, cin, kh, kw = weight.shape
     if cin % 32 != 0 or cout % 4 != 0:
@@ -1369,13 +1374,30 @@ def dense_seg_cycle(feat, target_region: int = 16, cyc_off: int = 2, chunk_size:
                             bool(soft_label))
 
 
-# contraction precision (process-wide): "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
-# "f16x3" = scaled split-fp16 (3 MFMAs per product)
+# contraction precision: "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
+# "f16x3" = scaled split-fp16 (3 MFMAs per product).  Host-side setting handed to the library with every call.
 PRECISIONS = ("f32", "bf16x6", "f16x3")
 # ----------------------------------------------------------------------------------------
 def set_precision(mode: str) -> None:
-    check(lib.glf_set_precision(PRECISIONS.index(mode)), "set_precision")
+    _PREC[0] = PRECISIONS.index(mode)
 
 
 def get_precision() -> str:
-    return PRECISIONS[int(lib.glf_get_precision())]
+    return PRECISIONS[_PREC[0]]
+
+
+class precision_scope:
+    """`with ops.precision_scope("f32"): ...` -- forward AND backward of whatever runs inside must both happen inside
+    the block (backward launches read the setting when they run)."""
+
+    def __init__(self, mode: str):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_precision()
+        set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+        return False

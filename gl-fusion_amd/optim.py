@@ -90,6 +90,7 @@ class Adam(torch.optim.Optimizer):
             lr = group["lr"]
             by_step: Dict[int, List[tuple]] = {}
             dev = None
+            updated = []
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -114,8 +115,13 @@ class Adam(torch.optim.Optimizer):
                 by_step.setdefault(t, []).append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                                   st["exp_avg_sq"].data_ptr(), p.numel()))
                 dev = p.device
+                updated.append(p)
             for t, entries in by_step.items():
                 table = self._tables.setdefault((gi, len(by_step) > 1 and t), _Table()).get(entries, dev)
                 check(lib.glf_adam_step(_p(table), table.shape[0], float(lr), float(b1), float(b2), float(group["eps"]),
                                         float(group["weight_decay"]), t, _stream()), "adam_step")
+            if updated:
+                # the kernel writes through raw pointers: tell autograd (and every cache keyed on `_version`: the
+                # tap-major / transposed / pre-split weight layouts and the measured maxima in ops.py) that these changed
+                torch.autograd.graph.increment_version(updated)
         return loss

@@ -8,15 +8,20 @@
  * (gl-fusion_amd/) binds them with ctypes from torch.autograd.Function wrappers.
  *
  * Conventions
- *   - plain pointers and sizes only; every device buffer is CALLER-OWNED (inputs, outputs,
- *     workspace, saved-for-backward).  The library never allocates or frees device memory
- *     and keeps no pointer after return.
+ *   - plain pointers and sizes only; every tensor and workspace buffer is CALLER-OWNED (inputs,
+ *     outputs, workspace, saved-for-backward) and no caller pointer is kept after return.  The
+ *     library owns exactly two kinds of small device allocations, made lazily and kept until the
+ *     process exits: a 1 MiB page of zeros per device (the split-fp16 kernels load conv-padding
+ *     and tile-overhang rows from it) and a 16 KiB ring of floats per (device, stream) that is
+ *     used only when a precision-3 contraction is called with amax_a / amax_b == NULL (the
+ *     library then measures the operand maxima itself, on that stream).
  *   - every function only ENQUEUES work on `stream` and returns; no host synchronisation.
  *   - return 0 on success, a negative glf_status otherwise; text via glf_last_error()
  *     (thread-local).  No exception crosses this boundary.
  *   - activations are channels-last: a tensor [N,H,W,C] is the row-major matrix
  *     [rows = N*H*W][C]; `ld*` arguments are row strides in elements.
- *   - arithmetic type: fp32 (v_mfma_f32_32x32x2_f32 for every contraction).
+ *   - arithmetic type: fp32 operands and results; contractions run on v_mfma_f32_32x32x2_f32 or on the
+ *     split 16-bit MFMA schemes selected per call / per process (see glf_set_precision).
  */
 #ifndef GLFUSION_H
 #define GLFUSION_H
@@ -45,7 +50,7 @@ int glf_abi_version(void);
 /* Queries the current device once (CU count) and raises the dynamic-LDS limit of the MFMA
  * kernels.  Optional: every entry point calls it lazily. */
 int glf_init(void);
-/* Contraction precision of glf_gemm_nt / glf_gemm_tn (process-wide):
+/* DEFAULT contraction precision of glf_gemm_nt / glf_gemm_tn, used by calls whose glf_gemm_params.precision is 0:
  *   0 = exact fp32 on v_mfma_f32_32x32x2_f32 (default);
  *   1 = split-bf16 "bf16x6": each fp32 operand is split into three bf16 pieces and six
  *       v_mfma_f32_32x32x16_bf16 reproduce the fp32 product to 2^-23 (fp32 accumulate) -- fp32-equivalent
@@ -113,6 +118,9 @@ typedef struct {
                                 /* the BatchNorm batch statistics of a conv output without a pass over it        */
                                 /* (finish with glf_bn_stats_from_sums).  A call that cannot honour it (exact    */
                                 /* kernels, rect = 1) fails with GLF_ERR_UNSUPPORTED instead of ignoring it.     */
+    int32_t precision;          /* contraction precision of THIS call: 0 = the process default (glf_set_precision), */
+                                /* 1 = exact fp32, 2 = split-bf16 x6, 3 = split-fp16 x3 (= 1 + the mode numbers of   */
+                                /* glf_set_precision).  Two models with different precisions can share a process.   */
 } glf_gemm_params;
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */

@@ -28,6 +28,7 @@ class _Tiny(torch.nn.Module):
         self.bn = torch.nn.BatchNorm2d(8)
         self.attn = orc.TPAVIModule(8, mode="dot")
         self.head = torch.nn.Conv2d(8, 5, 1)
+        self.spare = torch.nn.Conv2d(8, 1, 1)                # registered, NOT ignored, never used (e.g. Global_only's centerness heads)
 
     def forward(self, x):
         f = torch.relu(self.bn(self.stem(x)))
@@ -55,6 +56,8 @@ def _worker(rank, world, port, tmp):
     loss = bce(model(xs[lo:hi]), ts[lo:hi])
     loss.backward()
     red.finalize()
+    # a bucketed parameter that received no gradient keeps .grad None (the optimizer must skip it as on one GPU)
+    assert "spare.weight" in red.names and model.spare.weight.grad is None and model.spare.bias.grad is None
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     counts = all_reduce_counts(torch.tensor([rank + 1, 2, 3, 4]))
     torch.save({"grads": grads, "state": model.state_dict(), "range": (lo, hi), "counts": counts}, os.path.join(tmp, f"r{rank}.pt"))

@@ -92,9 +92,83 @@ def test_trainer_surface_runs_cycle_training_and_checkpoints(tmp_path):
     t.train(is_backbone=False, is_cycle=True)
     assert not torch.equal(before, t.model.classifier["1"][4].weight)
     ckpt = os.path.join(str(tmp_path), "net_00000.pth")
-    assert os.path.exists(ckpt) and open(os.path.join(str(tmp_path), "latest.ckpt")).read().strip() == "0"
+    assert os.path.exists(ckpt) and open(os.path.join(str(tmp_path), "latest.ckpt")).read().strip() == "00000"      # main.py:869 echoes the zero-padded epoch
     sd = torch.load(ckpt, map_location="cpu")["network"]              # main.py:857-872 format
     ref = orc.Global_and_Local(["1"])
     ref.load_state_dict(sd, strict=True)                               # the oracle (== reference key set) accepts it
     out = t.eval(net_path=ckpt)
     assert set(out) == {"1"} and all(np.isfinite(x) for x in out["1"])
+
+
+
+_ORACLE_TRAJ = []
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_three_adam_steps_see_fresh_weights(prec):
+    """Every weight-derived cache of the engine (tap-major / transposed / pre-split layouts, measured maxima) must be
+    refreshed after the fused Adam has written the parameters through raw pointers: three train steps (forward, fused
+    Adam, forward ...) against the oracle stepping with torch.optim.Adam, plus a direct check that a 3x3 conv and the
+    attention block evaluate with the UPDATED weights."""
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    from glfusion_amd.optim import Adam
+    ops.set_precision(prec)
+    try:
+        views, n = ["1"], 4
+        ref = orc.Global_and_Local(views)
+        orc.closed_form_fill(ref, salt=11)
+        orc.set_dropout(ref, 0.0)
+        model = Global_and_Local(views)
+        model.load_state_dict(ref.state_dict(), strict=True)
+        orc.set_dropout(model, 0.0)
+        model = model.to(DEV).train()
+        ref.train()
+        imgs = orc.closed_form_images(views, n, 112, 112)
+        tgts = orc.closed_form_targets(views, n)
+        dimgs = {v: t.to(DEV) for v, t in imgs.items()}
+        dtgts = {v: t.to(DEV) for v, t in tgts.items()}
+        lr = 1e-3
+        opt_ref = torch.optim.Adam([p for nm, p in ref.named_parameters() if not nm.startswith("network.")], lr=lr, weight_decay=1e-5)
+        opt = Adam([p for nm, p in model.named_parameters() if not nm.startswith("network.")], lr=lr, weight_decay=1e-5)
+        want, got = _ORACLE_TRAJ, []
+        for step in range(3):
+            if len(want) <= step:                         # the oracle's three steps run once for both precisions
+                pred = ref(imgs)[0]
+                l = sum(torch.nn.functional.binary_cross_entropy_with_logits(pred[v], tgts[v], reduction="sum") for v in views)
+                opt_ref.zero_grad()
+                l.backward()
+                opt_ref.step()
+                want.append(float(l.detach()))
+            pred = model(dimgs)[0]
+            l = sum(ops.bce_with_logits_sum(pred[v], dtgts[v]) for v in views)
+            opt.zero_grad(set_to_none=True)
+            l.backward()
+            opt.step()
+            got.append(float(l))
+            if step == 0:
+                # direct: a 3x3 conv (tap-major cache) and a dilated one evaluate with the weights Adam just wrote
+                for conv, cin, hw in ((model.layer1["1"][0].conv2, 64, 20), (model.layer4["1"][1].conv2, 512, 12)):
+                    x = orc.closed_form_tensor((2, cin, hw, hw), 900 + cin, -1.0, 1.0)
+                    with torch.no_grad():
+                        y = conv(x.to(DEV)).cpu()
+                        y_ref = torch.nn.functional.conv2d(x, conv.weight.detach().cpu(), None, conv.stride, conv.padding, conv.dilation)
+                    assert float((y - y_ref).abs().max()) <= 1e-4 * float(y_ref.abs().max()), "stale 3x3 weights after Adam.step()"
+                    # dgrad uses the cached transposed layout
+                    xg = x.to(DEV).requires_grad_(True)
+                    gy = orc.closed_form_tensor(tuple(y.shape), 901, -1.0, 1.0)
+                    conv(xg).backward(gy.to(DEV))
+                    xr = x.clone().requires_grad_(True)
+                    torch.nn.functional.conv2d(xr, conv.weight.detach().cpu(), None, conv.stride, conv.padding, conv.dilation).backward(gy)
+                    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max()), "stale dgrad weights after Adam.step()"
+                    conv.weight.grad = None
+        print("loss trajectory", got, "oracle", want)
+        assert abs(got[0] - want[0]) <= 2e-5 * abs(want[0])
+        # later steps: Adam's first updates are sign-like (lr * g / |g|), so entries whose gradient is rounding noise move
+        # either way and the trajectories separate at the 1e-4 level; stale 3x3 / transposed weights (the bug this guards
+        # against) leave the loss of step 1 where step 0 was, a relative difference of 1e-2 .. 1e-1 at this learning rate
+        assert abs(want[1] - want[0]) > 4 * 5e-3 * abs(want[0]), "the learning rate moves the loss too little for this test to discriminate"
+        for a, b in zip(got[1:], want[1:]):
+            assert abs(a - b) <= 5e-3 * abs(b), (got, want)
+    finally:
+        ops.set_precision("f32")
