@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: clips/sec forward+backward of GL-Fusion's hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or plainly -- the
+                                                        script then starts the N rank processes itself)
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): (B, V, T, H, W) = (4, 3, 16, 112, 112)
 per GPU, fp32, views ['1','3','4'] => N = B*T = 64 frames per view per rank; weak scaling (the per-GPU
@@ -12,8 +13,9 @@ default-init under torch.manual_seed(0) with the W_z BatchNorm gamma re-drawn N(
 branch is live.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     : dominant kernel's dense algorithmic FLOP/s (HIP events on the launch stream, timed region)
-                 vs the 157.3 TF fp32 MFMA peak
+  roofline     : dominant kernel's executed MFMA FLOP/s (HIP events around every launch, on the launch stream) vs the
+                 dense MFMA peak of the arithmetic it runs on, with its algorithmic bytes / FLOPs per launch
+  exact_f32    : the same step with every contraction on v_mfma_f32_32x32x2_f32, same --steps / --warmup, own roofline
   cpu_baseline : the oracle (CPU restatement) timed on the host cores on a bounded sample (N=1 run only)
 """
 from __future__ import annotations
@@ -110,6 +112,34 @@ def cpu_baseline(frames_per_view: int = 4, steps: int = 2):
                       f"{steps} timed step(s) after 1 warm-up, {dt:.2f} s/step, scaled per frame to a 16-frame clip"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes (one per GPU; RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, the same contract torch.distributed.run uses) BEFORE anything in this
+    process touches a GPU, relay rank 0's JSON line, and return non-zero if any rank fails.  No exec of a process that
+    has initialised the GPU is involved: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,11 +154,13 @@ def main():
                          "default) or f32 = exact v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: this process never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     if local_rank >= torch.cuda.device_count():
@@ -147,13 +179,17 @@ def main():
 
     from glfusion_amd import ops
     from glfusion_amd.ddp import GradAllReducer
-    ops.set_precision(args.precision)
 
     n_frames = args.clips * T
     model = build_model(dev)
     reducer = GradAllReducer(model)
     reducer.broadcast_parameters(0)
     imgs, tgts = make_batch(dev, rank, n_frames)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                       # how many ranks the collective backend really joined
+        ranks_seen = int(one.item())
 
     def step():
         for p in model.parameters():
@@ -172,59 +208,108 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    prof = []
-    ops.PROFILER = prof
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    ops.PROFILER = None
-    loss_val = float(loss)
-    if not (loss_val == loss_val and abs(loss_val) != float("inf")):
-        raise SystemExit(f"non-finite loss {loss_val}")
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
-    # The timed region runs the independent view chains on side streams, so its per-launch event intervals overlap
-    # (a launch's interval then includes time it shared the chip).  For a per-kernel figure that is a property of
-    # the kernel, repeat on ONE stream outside the timed region: 1 untimed step (the allocator's per-stream pools
-    # change) + up to 2 steps with the same per-launch events.
-    prof_iso, iso_steps = None, 0
-    if ops.STREAMS:
+    def run_leg(precision: str):
+        """W untimed warm-up steps, then EXACTLY K timed steps between two fences (no per-launch events inside the timed
+        region).  Then, outside the timed region, the per-kernel figures: 1 untimed + up to 2 steps on ONE stream with a
+        HIP event pair around every contraction launch (on side streams a launch's event interval would include the time
+        it shared the chip with other streams' kernels)."""
+        ops.set_precision(precision)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        loss_val = float(loss)
+        if not (loss_val == loss_val and abs(loss_val) != float("inf")):
+            raise SystemExit(f"non-finite loss {loss_val} ({precision})")
+        streams = ops.STREAMS
         ops.STREAMS = False
         step()
         fence()
-        prof_iso, iso_steps = [], min(2, args.steps)
-        ops.PROFILER = prof_iso
+        prof, iso_steps = [], min(2, args.steps)
+        ops.PROFILER = prof
         for _ in range(iso_steps):
             step()
         fence()
         ops.PROFILER = None
-        ops.STREAMS = True
+        ops.STREAMS = streams
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps}
 
-    # secondary figure, outside the timed region: the same step on the exact-fp32 MFMA kernels (2 steps)
-    exact = None
-    if args.precision != "f32" and not args.no_exact_f32:
-        ops.set_precision("f32")
-        step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        fence()
-        te = torch.tensor([(time.perf_counter() - t1) / 2], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        exact = {"value": round(args.clips * world / float(te.item()), 4), "unit": "clips/s", "ms_per_step": round(float(te.item()) * 1e3, 2),
-                 "arithmetic": "v_mfma_f32_32x32x2_f32 (exact fp32), same step, 2 timed steps after 1 warm-up"}
-        ops.set_precision(args.precision)
+    def roofline_of(leg):
+        precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
+        dump = os.environ.get("GLF_BENCH_DUMP")
+        if dump:
+            shapes = {}
+            for name, dense, kept, e0, e1, shp, abytes in prof:
+                r = shapes.setdefault((name,) + shp, [0, 0.0, dense, kept, abytes])
+                r[0] += 1
+                r[1] += e0.elapsed_time(e1)
+            with open(dump + "." + precision + ".csv", "w") as fh:
+                fh.write("kernel,M,N,K,taps,kept_taps,batch,split,pad,dil,launches_per_step,ms_per_step,avg_ms,dense_TF,executed_TF,algorithmic_GBps\n")
+                for key, (cnt, ms, dense, kept, abytes) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    fh.write('"' + key[0] + '",' + ",".join(str(x) for x in key[1:]) +
+                             f",{cnt // psteps},{ms / psteps:.3f},{ms / cnt:.4f},{dense * cnt / ms / 1e9:.1f},{kept * cnt / ms / 1e9:.1f},{abytes * cnt / ms / 1e6:.0f}\n")
+        agg = {}
+        for name, dense, kept, e0, e1, _shp, abytes in prof:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0, 0.0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += dense
+            a[2] += kept
+            a[3] += 1
+            a[4] += abytes
+        name, (secs, dense, kept, launches, abytes) = max(agg.items(), key=lambda kv: kv[1][0])
+        all_secs = sum(a[0] for a in agg.values())
+        all_dense = sum(a[1] for a in agg.values())
+        all_kept = sum(a[2] for a in agg.values())
+        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3}[precision]
+        # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
+        # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
+        #         16-bit FLOPs / time against the dense 16-bit MFMA peak (f16x3: THREE fp16 MFMA FLOPs per algorithmic FLOP)
+        if precision != "f32":
+            achieved, peak = nmul * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
+            fam = "bf16s" if precision == "bf16x6" else "f16s"
+            kname = name.replace("gemm_rows_kernel<0,", f"gemm_rows_{fam}8_kernel<").replace("gemm_tn_kernel<", f"gemm_tn_{fam}8_kernel<")
+        else:
+            achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
+        roofline = {
+            "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic_per_launch(kname, precision),
+            "algorithmic_bytes_per_launch": round(abytes / launches),
+            "algorithmic_flops_per_launch": round((dense if precision == "f32" else nmul * kept) / launches),
+            "arithmetic": {"f32": "v_mfma_f32_32x32x2_f32 (exact fp32)",
+                           "bf16x6": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate",
+                           "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate"}[precision],
+            "launches_per_step": launches // psteps, "avg_launch_ms": round(secs / launches * 1e3, 4),
+            "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
+            "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2),
+                                 "fp32_equiv_executed_tflops": round(all_kept / all_secs / 1e12, 2),
+                                 "mfma_frac_of_peak": round((all_dense if precision == "f32" else nmul * all_kept) / all_secs / 1e12 / peak, 4),
+                                 "s_per_step": round(all_secs / psteps, 4),
+                                 "per_kernel_s_per_step": {k: round(a[0] / psteps, 4) for k, a in sorted(agg.items())}},
+            "whole_step_dense_tflops": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
+            "measured": (f"HIP events around every launch of {psteps} step(s) on ONE stream right after the timed region (the timed "
+                         "region itself carries no per-launch events and runs the independent view chains on side streams)"),
+        }
+        if precision != "f32":
+            # profiles/r01_mfma_peak_microbench.txt: back-to-back 16-bit MFMAs with no memory traffic reach 2.47 PF on constant
+            # operands but 1.42-1.57 PF (fp16) on random ones -- on real data the matrix cores are power-limited
+            roofline["power_limited_peak_measured"] = {"value": 1500.0, "unit": "TFLOP/s", "frac": round(achieved / 1500.0, 4),
+                                                       "source": "profiles/ubench/mfma_peak.hip, random operands"}
+        return roofline
+
+    main_leg = run_leg(args.precision)
+    # second leg with the SAME --steps / --warmup: the strictly-fp32 step (v_mfma_f32_32x32x2_f32 everywhere), its own roofline
+    exact_leg = run_leg("f32") if (args.precision != "f32" and not args.no_exact_f32) else None
+    ops.set_precision(args.precision)
 
     # secondary figure (SURVEY row f2, outside the metric, which excludes the optimizer): the fused Adam step over
     # the gradients of the last backward -- HBM-bound, 16 B read + 12 B written per element
@@ -245,88 +330,19 @@ def main():
                       "unit": "GB/s", "frac": round(28.0 * adam_elems / adam_ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"}
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        clips_total = args.clips * world * args.steps
-        value = clips_total / dt
-        # ---- roofline of the dominant contraction kernel (HIP events recorded around every launch) -------
-        agg = {}
-        dump = os.environ.get("GLF_BENCH_DUMP")
-        if dump:
-            shapes = {}
-            for name, dense, kept, e0, e1, shp in (prof_iso or prof):
-                r = shapes.setdefault((name,) + shp, [0, 0.0, dense, kept])
-                r[0] += 1
-                r[1] += e0.elapsed_time(e1)
-            with open(dump, "w") as fh:
-                fh.write("kernel,M,N,K,taps,kept_taps,batch,split,pad,dil,launches,total_ms,avg_ms,dense_TF,executed_TF\n")
-                for key, (cnt, ms, dense, kept) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                    fh.write('"' + key[0] + '",' + ",".join(str(x) for x in key[1:]) + f",{cnt},{ms:.3f},{ms / cnt:.4f},{dense * cnt / ms / 1e9:.1f},{kept * cnt / ms / 1e9:.1f}\n")
-        def aggregate(records):
-            g = {}
-            for name, dense, kept, e0, e1, _shp in records:
-                a = g.setdefault(name, [0.0, 0.0, 0.0, 0])
-                a[0] += e0.elapsed_time(e1) * 1e-3
-                a[1] += dense
-                a[2] += kept
-                a[3] += 1
-            return g
-        # per-kernel figures come from the one-stream pass when the timed region overlapped its launches
-        agg_timed = aggregate(prof)
-        agg = aggregate(prof_iso) if prof_iso else agg_timed
-        psteps = iso_steps if prof_iso else args.steps
-        dom = max(agg.items(), key=lambda kv: kv[1][0])
-        name, (secs, dense, kept, launches) = dom
-        all_secs = sum(a[0] for a in agg.values())
-        all_dense = sum(a[1] for a in agg.values())
-        split = args.precision != "f32"
-        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3}[args.precision]
-        # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
-        # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
-        #         bf16 FLOPs / time against the dense bf16 MFMA peak; the fp32-equivalent rates are given beside it
-        #         (f16x3: THREE fp16 MFMA FLOPs per algorithmic FLOP, same dense 16-bit peak)
-        if split:
-            achieved, peak = nmul * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
-            fam = "bf16s" if args.precision == "bf16x6" else "f16s"
-            kname = name.replace("gemm_rows_kernel<0,", f"gemm_rows_{fam}8_kernel<").replace("gemm_tn_kernel<", f"gemm_tn_{fam}_kernel<")
-        else:
-            achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
-        roofline = {
-            "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic_per_launch(kname, args.precision),
-            "arithmetic": {"f32": "v_mfma_f32_32x32x2_f32 (exact fp32)",
-                           "bf16x6": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate",
-                           "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate"}[args.precision],
-            "launches_per_step": launches // psteps, "avg_launch_ms": round(secs / launches * 1e3, 4),
-            "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
-            "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2),
-                                 "s_per_step": round(all_secs / psteps, 4),
-                                 "per_kernel_s_per_step": {k: round(a[0] / psteps, 4) for k, a in sorted(agg.items())}},
-            "whole_step_dense_tflops": round(DENSE_GFLOP_PER_FRAME_FWD * 3 * n_frames * 1e9 / (dt / args.steps) / 1e12, 2),
-        }
-        if split:
-            # profiles/r01_mfma_peak_microbench.txt: back-to-back 16-bit MFMAs with no memory traffic reach 2.47 PF on constant
-            # operands but 1.42-1.57 PF (fp16) on random ones -- on real data the matrix cores are power-limited
-            roofline["power_limited_peak_measured"] = {"value": 1500.0, "unit": "TFLOP/s", "frac": round(achieved / 1500.0, 4),
-                                                       "source": "scratch/ubench/mfma_peak.hip, random operands"}
-        if prof_iso:
-            tsecs, tdense, tkept, tlaunch = agg_timed[name]
-            roofline["measured"] = (f"HIP events around every launch, {iso_steps} step(s) on ONE stream right after the timed region: "
-                                    "the timed region runs the independent view chains on side streams, where a launch's event "
-                                    "interval includes the time it shared the chip with other streams' kernels")
-            roofline["timed_region_overlapped"] = {
-                "avg_launch_ms": round(tsecs / tlaunch * 1e3, 4), "launches_per_step": tlaunch // args.steps,
-                "sum_of_contraction_intervals_over_step_time": round(sum(a[0] for a in agg_timed.values()) / dt, 3)}
-        else:
-            roofline["measured"] = "HIP events around every launch over the timed region (one stream)"
+        dt = main_leg["dt"]
         out = {
-            "metric": "clips/sec fwd+bwd (B=4, 3 views x16x112x112) per GPU, weak scaling", "value": round(value, 4),
+            "metric": "clips/sec fwd+bwd (B=4, 3 views x16x112x112) per GPU, weak scaling",
+            "value": round(args.clips * world * args.steps / dt, 4),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
                        "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
-                       "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU"},
+                       "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU",
+                       "ranks_in_collective": ranks_seen,
+                       "collective_backend": (os.environ.get("GLF_DIST_BACKEND", "nccl") if world > 1 else None)},
             "numerics": {"f32": "exact fp32 MFMA",
                          "bf16x6": "fp32 operands and results; each product = 6 bf16 MFMAs on an exact 3-way split, fp32 accumulate; "
                                    "K=2048 GEMM error vs fp64 3.4e-7 (exact fp32 kernel 3.2e-7)",
@@ -334,11 +350,15 @@ def main():
                                   "accumulate; K=2048 GEMM error vs fp64 7e-7 (exact fp32 kernel 3e-7); every parity gate of tests/ "
                                   "(masks / Dice within 1e-4 of the fp32 reference, gradients within its fp32-vs-fp64 noise) passes "
                                   "under this mode; the exact-fp32 step is reported as exact_f32"}[args.precision],
-            "loss": loss_val, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-            "roofline": roofline,
+            "loss": main_leg["loss"], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+            "roofline": roofline_of(main_leg),
         }
-        if exact is not None:
-            out["exact_f32"] = exact
+        if exact_leg is not None:
+            out["exact_f32"] = {"value": round(args.clips * world * args.steps / exact_leg["dt"], 4), "unit": "clips/s",
+                                "ms_per_step": round(exact_leg["dt"] / args.steps * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
+                                "dtype": "f32", "loss": exact_leg["loss"],
+                                "arithmetic": "v_mfma_f32_32x32x2_f32 (exact fp32) for every contraction, same step, same --steps / --warmup",
+                                "roofline": roofline_of(exact_leg)}
         out["optimizer_step"] = optimizer_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

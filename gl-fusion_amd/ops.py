@@ -153,11 +153,17 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     if prof is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        # dense, reference-equivalent FLOPs of this launch (every tap, padding included) and the FLOPs of the
-        # taps the host-side mask keeps
+        # dense, reference-equivalent FLOPs of this launch (every tap, padding included), the FLOPs of the taps the
+        # host-side mask keeps, and the ALGORITHMIC bytes: every operand element read once, every result written once
+        kept_taps = bin(mask).count("1")
         dense = 2.0 * M * N * K * taps * batch
-        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * bin(mask).count("1") / taps, ev0, ev1,
-                     (M, N, K, taps, bin(mask).count("1"), batch, split, geo[8] if geo else 0, geo[9] if geo else 0)))
+        src_rows = (geo[0] * geo[1] * geo[2]) if geo else None
+        if mode == "tn":
+            abytes = 4.0 * batch * (K * M + (src_rows if src_rows else K) * N + M * N * kept_taps)
+        else:
+            abytes = 4.0 * batch * ((src_rows if src_rows else M) * K + N * K * kept_taps + M * N * (2 if accumulate else 1))
+        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * kept_taps / taps, ev0, ev1,
+                     (M, N, K, taps, kept_taps, batch, split, geo[8] if geo else 0, geo[9] if geo else 0), abytes))
 
 
 def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

@@ -514,6 +514,44 @@ def closed_form_fill(module: nn.Module, salt: int = 0) -> None:
             t.copy_(closed_form_tensor(t.shape, s, -0.05, 0.05))
 
 
+@torch.no_grad()
+def kinkfree_fill(module: nn.Module, salt: int = 0, offset: float = 6.0) -> None:
+    """closed_form_fill, then every BatchNorm2d gets beta_c = +offset (even c) / -offset (odd c) and gamma in 1 +- 0.1.
+    In train() a BatchNorm output is gamma * z + beta with z of exactly zero mean and unit variance per channel, so every
+    ReLU input sits at +-offset +- ~1: no pre-activation comes within rounding distance of zero, no ReLU mask can differ
+    between two floating-point evaluations (fp32 / fp64 / split-fp16), and channels of the same index keep the same sign
+    across a residual join (identity and bn3 branch are both dead, or both alive).  Gradients of a step on such weights
+    are smooth functions of the arithmetic: the reference's own fp32-vs-fp64 deviation is ~1e-6, which lets the parity
+    tests gate every parameter gradient tightly instead of allowing for flipped masks."""
+    closed_form_fill(module, salt)
+    for k, m in enumerate(module.modules()):
+        if isinstance(m, nn.BatchNorm2d):
+            c = m.num_features
+            sign = torch.where(torch.arange(c) % 2 == 0, 1.0, -1.0)
+            m.bias.copy_(sign * offset + closed_form_tensor((c,), salt * 7919 + k, -0.05, 0.05))
+            m.weight.copy_(closed_form_tensor((c,), salt * 7927 + k, 0.9, 1.1))
+        elif isinstance(m, nn.Conv2d) and m.out_channels == 1 and m.bias is not None:
+            # the 1-channel centre-ness logit: small weights and bias -3 => c = sigmoid(.) ~ 0.05, which keeps the local
+            # gate sigmoid(20 m c) (ours.py:1814) away from saturation: gradients do reach the centerness heads through it
+            m.weight.mul_(0.02)
+            m.bias.fill_(-3.0)
+
+
+def varied_images(views: Sequence[str], n: int, h: int = 112, w: int = 112, salt: int = 13):
+    """Frames that differ strongly from each other (per-frame gain 0.25 .. 1 and a per-frame gradient) so that statistics
+    taken ACROSS frames -- the ASPP pooled branch normalises N frame averages per channel -- are well-conditioned."""
+    out = {}
+    yy = torch.linspace(0.0, 1.0, h).view(1, 1, h, 1)
+    xx = torch.linspace(0.0, 1.0, w).view(1, 1, 1, w)
+    for i, v in enumerate(views):
+        base = closed_form_tensor((n, 1, h, w), salt * 1000 + i)
+        f = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1)
+        gain = 0.25 + 0.75 * ((f * 5 + i * 3) % n) / max(n - 1, 1)
+        ramp = 0.5 * (torch.cos(f * 1.7 + i) * yy + torch.sin(f * 2.3 + i) * xx)
+        out[v] = (gain * base + 0.25 * ramp + 0.25).clamp_(0.0, 1.0).contiguous()
+    return out
+
+
 def closed_form_images(views: Sequence[str], n: int, h: int = 112, w: int = 112, salt: int = 7):
     return {v: closed_form_tensor((n, 1, h, w), salt * 1000 + i) for i, v in enumerate(views)}
 

@@ -56,7 +56,7 @@ def sample_idx(n: int, k: int = 257) -> np.ndarray:
 
 
 def t2n(t: torch.Tensor) -> np.ndarray:
-    return t.detach().cpu().contiguous().numpy()
+    return t.detach().cpu().contiguous().numpy().copy()       # a copy: never an alias of module state
 
 
 def grads_summary(model: torch.nn.Module):
@@ -202,6 +202,88 @@ def main() -> None:
     print("train loss", float(loss))
 
 
+def bottleneck_fixture() -> None:
+    """the reference's OWN in-tree Bottleneck (models/resnet.py:43-79 -- the block torchvision's
+    ResNet-50 is made of, stride on the 3x3, no dilation argument), train-mode forward / backward / running statistics,
+    for the identity-shortcut form and the stride-2 + downsample form (models/resnet.py:110-117)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_resnet", os.path.join(REF, "models", "resnet.py"))
+    ref_resnet = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_resnet)
+    d = {}
+    for tag, (inplanes, planes, stride, hw) in {"plain": (64, 16, 1, 14), "down": (64, 32, 2, 15)}.items():
+        for dt, sfx in ((torch.float32, ""), (torch.float64, "64")):
+            down = None
+            if stride != 1 or inplanes != planes * 4:           # models/resnet.py:110-117
+                down = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                           torch.nn.BatchNorm2d(planes * 4))
+            blk = ref_resnet.Bottleneck(inplanes, planes, stride, down)
+            orc.closed_form_fill(blk, salt=31)
+            blk = blk.to(dt).train()
+            x = orc.closed_form_tensor((4, inplanes, hw, hw), 311, -1.0, 1.0).to(dt).requires_grad_(True)
+            y = blk(x)
+            gy = orc.closed_form_tensor(tuple(y.shape), 312, -1.0, 1.0).to(dt)
+            y.backward(gy)
+            d[f"{tag}:y{sfx}"] = t2n(y.float())
+            d[f"{tag}:dx{sfx}"] = t2n(x.grad.float())
+            for k, p_ in blk.named_parameters():
+                d[f"{tag}:g{sfx}:{k}"] = t2n(p_.grad.float())
+            if not sfx:
+                d[f"{tag}:cfg"] = np.array([inplanes, planes, stride, hw])
+                d[f"{tag}:keys"] = np.array(list(blk.state_dict().keys()))
+                for k, v in blk.state_dict().items():
+                    if "running" in k or "num_batches" in k:
+                        d[f"{tag}:bn:{k}"] = t2n(v.float())
+                blk.eval()
+                with torch.no_grad():
+                    d[f"{tag}:y_eval"] = t2n(blk(x.detach()))
+        print("bottleneck", tag, "|y|max", float(np.abs(d[f"{tag}:y"]).max()))
+    np.savez_compressed(os.path.join(HERE, "bottleneck_ref.npz"), **d)
+
+
+def kinkfree_fixture(ours) -> None:
+    """A train step whose gradients are smooth in the arithmetic (oracle.kinkfree_fill: no ReLU input near zero), executed
+    by the reference in fp32 and fp64: per-parameter gradient norms, 65-point gradient samples, logits samples."""
+    views, n = ["1", "3"], 8
+    imgs = orc.varied_images(views, n)
+    tgts = orc.closed_form_targets(views, n)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="sum")
+    d = {"views": np.array(views), "n": np.array(n)}
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        model = ours.Global_and_Local(view_num=views)
+        orc.kinkfree_fill(model, salt=21)
+        orc.set_dropout(model, 0.0)
+        model = model.to(dt).train()
+        pred = model({v: imgs[v].to(dt) for v in views})[0]
+        loss = sum(bce(pred[v], tgts[v].to(dt)) for v in views)
+        loss.backward()
+        d["loss" + sfx] = np.array(float(loss.detach()))
+        names, norms = [], []
+        for name, p_ in model.named_parameters():
+            names.append(name)
+            if p_.grad is None:
+                norms.append(-1.0)
+                continue
+            g = p_.grad.detach().double().reshape(-1)
+            norms.append(float(g.norm()))
+            if sfx == "64":
+                d["g64:" + name] = t2n(g[torch.from_numpy(sample_idx(g.numel(), 65))].float())
+        d["grad_names"] = np.array(names)
+        d["grad_norms" + sfx] = np.array(norms)
+        for v in views:
+            flat = pred[v].detach().reshape(-1)
+            d[f"mask{sfx}:{v}"] = t2n(flat[torch.from_numpy(sample_idx(flat.numel(), 20011))].float())
+        if sfx == "32":
+            sd = model.state_dict()
+            for k in sd:
+                if ("running_mean" in k or "running_var" in k) and not k.startswith("network."):
+                    flat = sd[k].reshape(-1).float()
+                    d["bn:" + k] = t2n(flat[torch.from_numpy(sample_idx(flat.numel(), 9))])
+        print("kinkfree", sfx, "loss", float(loss.detach()))
+        del model, pred, loss
+    np.savez_compressed(os.path.join(HERE, "e2e_train_kinkfree.npz"), **d)
+
+
 def variants_fixture(ours) -> None:
     """the two single-branch ablations, eval() outputs of the reference's own classes."""
     views, n = ["1", "3"], 2
@@ -275,8 +357,13 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if not args or "cycle" in args:
         cycle_fixture()
+    if not args or "bottleneck" in args:
+        bottleneck_fixture()
+    if not args or "kinkfree" in args:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        kinkfree_fixture(import_reference()[0])
     if not args or "variants" in args:
         torch.set_num_threads(max(1, os.cpu_count() or 1))
         variants_fixture(import_reference()[0])
-    if not args or set(args) - {"cycle", "variants"}:
+    if not args or set(args) - {"cycle", "variants", "bottleneck", "kinkfree"}:
         main()

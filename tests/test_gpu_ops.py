@@ -381,3 +381,85 @@ def test_f16x3_contraction_accuracy_over_the_fp32_range(sa, sb):
         assert float(slot) == float(c.abs().max())                       # epilogue by-product: max |C|
     finally:
         ops.set_precision("f32")
+
+
+# ------------------------------------------------------------------------------------------ real model shapes
+def _rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm()) / max(float(b.norm()), 1e-30)
+
+
+REAL_CONVS = [
+    # n, h, w, cin, cout, k, pad, dil      (the contractions that dominate backward at C2: full channel counts)
+    (8, 28, 28, 2048, 256, 3, 12, 12),     # ASPP rate 12: per-tap rectangles (fwd / wgrad), dense or region dgrad
+    (8, 28, 28, 2048, 256, 3, 24, 24),     # ASPP rate 24
+    (8, 28, 28, 2048, 256, 3, 36, 36),     # ASPP rate 36: centre tap only
+    (8, 28, 28, 512, 512, 3, 4, 4),        # layer4 conv2
+    (192, 28, 28, 1024, 2048, 1, 0, 1),    # W_z of the fusion block at C2: M = 64 frames x 3 views x 784 = 150 528 rows
+]
+
+
+@pytest.mark.parametrize("cfg", REAL_CONVS)
+def test_conv2d_real_shapes_fwd_dgrad_wgrad(ops, cfg):
+    """forward, dgrad and wgrad at the 2048-channel model shapes against torch's CPU fp32 convolution (oneDNN), each gated
+    at 5e-5 in relative L2 -- the bound that protects the reductions (a wgrad that dropped 0.5 % of its rows is at 5e-3)."""
+    n, h, w, cin, cout, k, pad, dil = cfg
+    torch.set_num_threads(max(1, __import__("os").cpu_count() or 1))
+    x = rnd(n, cin, h, w, seed=20).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=21) / np.sqrt(cin * k * k)).requires_grad_(True)
+    y_ref = F.conv2d(x, wt, None, stride=1, padding=pad, dilation=dil)
+    gy = rnd(*y_ref.shape, seed=22)
+    y_ref.backward(gy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    wd = wt.detach().to(DEV).requires_grad_(True)
+    y = ops.conv2d(xh, wd, None, 1, pad, dil)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert _rel_l2(y.permute(0, 3, 1, 2), y_ref) <= 5e-5
+    assert _rel_l2(xh.grad.permute(0, 3, 1, 2), x.grad) <= 5e-5
+    assert _rel_l2(wd.grad, wt.grad) <= 5e-5
+
+
+# ------------------------------------------------------------------------------------------ f16x3 range adversaries
+def test_f16x3_outlier_and_small_view_operands():
+    """The split-fp16 kernels scale each operand by ONE power of two taken from its maximum.  Adversaries: (a) a gradient
+    tensor with a single 1e6 outlier (every other element sits 2^20 below the scale), (b) a stacked activation tensor in
+    which one view is 2^30 smaller than the others.  Results must stay at fp32 level: 1e-5 relative L2 per output slice
+    against fp64 for (a); for (b) the small view's rows keep >= 19 bits (error relative to THAT view's magnitude <= 1e-5)."""
+    from glfusion_amd import ops as _ops
+    _ops.set_precision("f16x3")
+    try:
+        n, h, w, cin, cout = 2, 28, 28, 256, 256
+        x = rnd(n, h, w, cin, seed=30)
+        wt = rnd(cout, cin, 3, 3, seed=31) / np.sqrt(cin * 9)
+        gy = rnd(n, h, w, cout, seed=32)
+        r0, c0 = 777, 13
+        gy.view(-1, cout)[r0, c0] = 1.0e6
+        xd = x.to(DEV).requires_grad_(True)
+        wd = wt.to(DEV).requires_grad_(True)
+        _ops.conv2d(xd, wd, None, 1, 2, 2).backward(gy.to(DEV))
+        x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+        w64 = wt.double().requires_grad_(True)
+        F.conv2d(x64, w64, None, 1, 2, 2).backward(gy.double().permute(0, 3, 1, 2))
+        dx_ref = x64.grad.permute(0, 2, 3, 1)
+        # dgrad rows that the outlier touches (its 3x3 dilated footprint) and all the others, separately
+        touched = (dx_ref.abs().amax(dim=3) > 1e3)
+        assert 1 <= int(touched.sum()) <= 9
+        assert _rel_l2(xd.grad[touched.to(DEV)], dx_ref[touched]) <= 1e-5
+        assert _rel_l2(xd.grad[(~touched).to(DEV)], dx_ref[~touched]) <= 1e-5
+        # wgrad: the outlier's output channel and all the others, separately
+        others = [c for c in range(cout) if c != c0]
+        assert _rel_l2(wd.grad[c0], w64.grad[c0]) <= 1e-5
+        assert _rel_l2(wd.grad[others], w64.grad[others]) <= 1e-5
+
+        # (b) rows of one view 2^30 below the rest inside one operand (one amax for the whole tensor)
+        rows, k, nn_ = 3 * 784, 512, 256
+        a = rnd(rows, k, seed=33)
+        a[784:1568] *= 2.0 ** -30
+        b = rnd(nn_, k, seed=34) / np.sqrt(k)
+        c = torch.empty(rows, nn_, device=DEV)
+        _ops.gemm("nt", a.to(DEV), b.to(DEV), c, M=rows, N=nn_, K=k, lda=k, ldb=k, ldc=nn_)
+        ref = a.double() @ b.double().t()
+        assert _rel_l2(c[:784], ref[:784]) <= 2e-6 and _rel_l2(c[1568:], ref[1568:]) <= 2e-6
+        assert _rel_l2(c[784:1568], ref[784:1568]) <= 1e-5          # 2^-49 amax absolute floor = 2^-19 of this view
+    finally:
+        _ops.set_precision("f32")

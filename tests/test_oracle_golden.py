@@ -171,3 +171,92 @@ def test_oracle_variants_match_reference_fixture(golden_dir, name):
             idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(20011, flat.numel())).astype(np.int64))
             got = flat[torch.from_numpy(idx)]
             assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (key, v)
+
+
+def _bottleneck_pair(cls, conv, bn, inplanes, planes, stride):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = torch.nn.Sequential(conv(inplanes, planes * 4, kernel_size=1, stride=stride, bias=False), bn(planes * 4))
+    return cls(inplanes, planes, stride, down)
+
+
+@pytest.mark.parametrize("tag", ["plain", "down"])
+def test_bottleneck_vs_reference_block(golden_dir, tag):
+    """the oracle's Bottleneck against the reference's own in-tree block (models/resnet.py:43-79; fixture
+    produced by executing it): train-mode forward, input / parameter gradients, running statistics, eval forward.
+    What stays unpinned is torchvision's dilation rule of `_make_layer` (the in-tree block has no dilation argument)."""
+    g = np.load(os.path.join(golden_dir, "bottleneck_ref.npz"))
+    inplanes, planes, stride, hw = [int(v) for v in g[f"{tag}:cfg"]]
+    blk = _bottleneck_pair(orc.Bottleneck, torch.nn.Conv2d, torch.nn.BatchNorm2d, inplanes, planes, stride)
+    assert list(blk.state_dict().keys()) == [str(k) for k in g[f"{tag}:keys"]]
+    orc.closed_form_fill(blk, salt=31)
+    blk.train()
+    x = orc.closed_form_tensor((4, inplanes, hw, hw), 311, -1.0, 1.0).requires_grad_(True)
+    y = blk(x)
+    y.backward(orc.closed_form_tensor(tuple(y.shape), 312, -1.0, 1.0))
+    assert close(y.detach(), g[f"{tag}:y"], 1e-6)
+    assert close(x.grad, g[f"{tag}:dx"], 1e-5)
+    for k, p in blk.named_parameters():
+        ref = torch.from_numpy(g[f"{tag}:g:{k}"]).double()
+        assert float((p.grad.double() - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-7, k
+    for k, v in blk.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert close(v.float(), g[f"{tag}:bn:{k}"], 1e-6), k
+    blk.eval()
+    with torch.no_grad():
+        assert close(blk(x.detach()), g[f"{tag}:y_eval"], 1e-6)
+
+
+def kinkfree_gate(name, got, want64, scale):
+    """relative L2 of a gradient against the fp64 reference; `scale` is the largest gradient norm of the parameter's
+    top-level module (structurally-zero gradients -- a bias in front of a train-mode BatchNorm -- hold rounding noise only)."""
+    return float((got.double() - want64.double()).norm()), 1e-3 * float(want64.double().norm()) + 1e-5 * scale
+
+
+def test_kinkfree_train_step_oracle_vs_reference(golden_dir):
+    """The oracle's train step on the kink-free weights (no ReLU input near zero => gradients smooth in the arithmetic)
+    against the reference's fp64 evaluation of the same step: loss, logits, every parameter's gradient norm, 65-point
+    gradient samples, BatchNorm running statistics."""
+    g = np.load(os.path.join(golden_dir, "e2e_train_kinkfree.npz"))
+    views, n = [str(v) for v in g["views"]], int(g["n"])
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    model = orc.Global_and_Local(views)
+    orc.kinkfree_fill(model, salt=21)
+    orc.set_dropout(model, 0.0)
+    model.train()
+    imgs, tgts = orc.varied_images(views, n), orc.closed_form_targets(views, n)
+    pred = model(imgs)[0]
+    loss = sum(torch.nn.functional.binary_cross_entropy_with_logits(pred[v], tgts[v], reduction="sum") for v in views)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss64"])) <= 1e-6 * float(g["loss64"])
+    # the reference's own fp32-vs-fp64 noise on this fixture, for the record (and as a guard on the fixture's conditioning)
+    n32, n64 = g["grad_norms32"], g["grad_norms64"]
+    live = n64 > 1e-6 * n64.max()
+    assert np.median(np.abs(n32[live] - n64[live]) / n64[live]) < 1e-5
+    for v in views:
+        flat = pred[v].detach().reshape(-1)
+        idx = np.unique(np.linspace(0, flat.numel() - 1, num=20011).astype(np.int64))
+        assert close(flat[torch.from_numpy(idx)], g[f"mask64:{v}"], 1e-4), v
+    names = [str(k) for k in g["grad_names"]]
+    norms64 = dict(zip(names, n64.tolist()))
+    scale = {}
+    for k, v in norms64.items():
+        scale[k.split(".")[0]] = max(scale.get(k.split(".")[0], 0.0), v)
+    for name, p in model.named_parameters():
+        if norms64[name] < 0:
+            assert p.grad is None, name
+            continue
+        gn = float(p.grad.double().norm())
+        tol = 1e-3 * norms64[name] + 1e-5 * scale[name.split(".")[0]]
+        assert abs(gn - norms64[name]) <= tol, (name, gn, norms64[name])
+        flat = p.grad.reshape(-1)
+        idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(65, flat.numel())).astype(np.int64))
+        want = torch.from_numpy(g["g64:" + name]).double()
+        err = float((flat[torch.from_numpy(idx)].double() - want).norm())
+        assert err <= 1e-3 * float(want.norm()) + tol * (len(idx) / flat.numel()) ** 0.5 + 1e-12, (name, err, float(want.norm()))
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("bn:"):
+            flat = sd[k[3:]].reshape(-1).float()
+            idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(9, flat.numel())).astype(np.int64))
+            assert close(flat[torch.from_numpy(idx)], g[k], 1e-5), k
