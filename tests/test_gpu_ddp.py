@@ -75,3 +75,92 @@ def test_two_ranks_match_single_process(tmp_path):
         t = truth[n].grad.detach().float().cpu().double()
         err = float((g0.double() - t).norm()) / max(float(t.norm()), 1e-12)
         assert err <= 5e-4, (n, err)                                          # == gradient of the global SUM loss
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 4 (BASELINE.json configs[3]): batch 32 over 8 GPUs = 4 clips of 16 frames x 3 views PER RANK.  Two such
+# ranks fit the one GPU of the test box (2 x 58 GB): the per-rank workload is exactly C4's.
+# ------------------------------------------------------------------------------------------------------------
+C4_VIEWS = ["1", "3", "4"]
+C4_FRAMES = 64                      # per view per rank: B_local = 4 clips x T = 16
+
+
+def _c4_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import glfusion_ref as orc
+    from glfusion_amd import ops
+    from glfusion_amd.ddp import GradAllReducer
+    from glfusion_amd.models import Global_and_Local
+    ops.set_precision("f16x3")                                   # the bench's default contraction kernels
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = Global_and_Local(C4_VIEWS)
+    with torch.no_grad():
+        for attn in (model.global_attn, model.local_attn):
+            attn.W_z[1].weight.normal_(1.0, 0.1)
+    orc.set_dropout(model, 0.0)                                  # two identical passes below
+    model = model.to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)     # bench.py's per-rank synthetic shard
+    imgs = {v: torch.rand(C4_FRAMES, 1, 112, 112, device=dev, generator=g) for v in C4_VIEWS}
+    tgts = {v: (torch.rand(C4_FRAMES, 5, 112, 112, device=dev, generator=g) < 0.3).float() for v in C4_VIEWS}
+    keep = lambda n: n.endswith("layer4.1.0.conv2.weight") or n.startswith("global_attn.theta") or n.endswith("classifier.3.4.weight") or n.startswith("init_block.4.0")
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        pred = model(imgs)[0]
+        loss = sum(ops.bce_with_logits_sum(pred[v], tgts[v]) for v in C4_VIEWS)
+        loss.backward()
+        return float(loss.detach())
+
+    loss_local = step()                                          # 1: this rank's own gradients (no exchange)
+    local = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None and keep(n)}
+    red = GradAllReducer(model)                                  # default 48 MB buckets, as bench.py / engine.Trainer
+    red.broadcast_parameters(0)
+    loss = step()                                                # 2: same batch, hooks armed
+    red.finalize()
+    torch.cuda.synchronize()
+    reduced = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None and keep(n)}
+    torch.save({"loss": loss, "loss_local": loss_local, "local": local, "reduced": reduced,
+                "n_grads": sum(p.grad is not None for p in model.parameters()), "peak_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
+               os.path.join(tmp, f"c4_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_config4_two_ranks_at_c2_frame_counts(tmp_path):
+    """Each of two ranks runs the full C2-sized shard (3 views x 64 frames, train mode) and exchanges gradients: the
+    reduced gradient is the SUM of the ranks' own gradients, identical on both ranks; losses are finite."""
+    world = 2
+    mp.spawn(_c4_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"c4_{i}.pt") for i in range(world)]
+    for i in range(world):
+        assert r[i]["loss"] == r[i]["loss"] and abs(r[i]["loss"]) < 1e12
+        assert abs(r[i]["loss"] - r[i]["loss_local"]) <= 1e-6 * abs(r[i]["loss"])     # same batch, same batch statistics
+    assert r[0]["n_grads"] == r[1]["n_grads"] > 900
+    assert len(r[0]["reduced"]) >= 4
+    for n, g0 in r[0]["reduced"].items():
+        assert torch.equal(g0, r[1]["reduced"][n]), n
+        want = r[0]["local"][n].double() + r[1]["local"][n].double()
+        assert float((g0.double() - want).norm()) <= 1e-5 * float(want.norm()), n     # wgrad split-K atomics reorder sums between passes
+    print("config-4 rank peak memory (GB):", [round(x["peak_gb"], 1) for x in r])
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no torch.distributed.run): the script starts its own rank
+    processes, both join the collective, rank 0 prints the JSON line.  gloo here (one GPU on the test box; RCCL wants
+    one device per rank), one clip per rank to keep it short."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GLF_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "1",
+                          "--no-exact-f32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_collective"] == 2
+    assert line["config"]["global_batch_clips"] == 2 and line["value"] > 0 and line["scaling"] == "weak"

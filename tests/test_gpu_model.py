@@ -532,3 +532,61 @@ def test_temporal_variant_vs_oracle():
     gg = model.global_attn.g.weight.grad.double().cpu()
     _ops.set_precision("f32")
     assert float((gg - gw).norm()) <= 3e-2 * float(gw.norm())          # fp32 gradient noise of this network: see test_gpu_engine
+
+
+# ------------------------------------------------------------------------------------------------------------
+# config 5 (BASELINE.json configs[4]): 5 views x 224 x 224 => h = w = 56, L = V h w = 15 680 positions per frame
+# ------------------------------------------------------------------------------------------------------------
+C5_VIEWS = ["1", "2", "3", "4", "5"]
+
+
+def test_config5_shape_eval_parity_and_linearity():
+    """At the stress shape: (a) eval forward of ONE frame against the oracle (which materialises the 15 680 x 15 680
+    score matrix the engine never forms), logits within 1e-4; (b) size-independent property at T = 4: with eval-mode
+    BatchNorm frames are independent, so the gradient of the SUM loss over four frames equals the sum of the gradients
+    over two halves; (c) a train() step at T = 4 is finite and every live parameter receives a gradient."""
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    ops.set_precision("f16x3")
+    try:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        ref = orc.Global_and_Local(C5_VIEWS)
+        orc.closed_form_fill(ref, salt=4)
+        ref.eval()
+        model = Global_and_Local(C5_VIEWS)
+        model.load_state_dict(ref.state_dict(), strict=True)
+        model = model.to(DEV).eval()
+        imgs = orc.closed_form_images(C5_VIEWS, 4, 224, 224)
+        tgts = orc.closed_form_targets(C5_VIEWS, 4, 5, 224, 224)
+        dimgs = {v: t.to(DEV) for v, t in imgs.items()}
+        dtgts = {v: t.to(DEV) for v, t in tgts.items()}
+        with torch.no_grad():
+            want = ref({v: t[:1] for v, t in imgs.items()})
+            got = model({v: t[:1] for v, t in dimgs.items()})
+        for v in C5_VIEWS:
+            assert tuple(got[0][v].shape) == (1, 5, 224, 224) and tuple(got[2][v].shape) == (1, 2048, 56, 56)
+            assert close(got[0][v], want[0][v]), v
+            assert close(got[1][v], want[1][v]), v
+
+        def grads(lo, hi):
+            for p in model.parameters():
+                p.grad = None
+            pred = model({v: t[lo:hi] for v, t in dimgs.items()})[0]
+            loss = sum(ops.bce_with_logits_sum(pred[v], dtgts[v][lo:hi]) for v in C5_VIEWS)
+            loss.backward()
+            return float(loss), {n: p.grad.detach().double() for n, p in model.named_parameters() if p.grad is not None}
+        l_all, g_all = grads(0, 4)
+        l_a, g_a = grads(0, 2)
+        l_b, g_b = grads(2, 4)
+        assert abs(l_all - (l_a + l_b)) <= 1e-6 * abs(l_all)
+        assert len(g_all) > 1500
+        for n, g in g_all.items():
+            s = g_a[n] + g_b[n]
+            assert float((g - s).norm()) <= 1e-4 * float(g.norm()) + 1e-7 * float(g_all["classifier.1.4.weight"].norm()), n
+        orc.set_dropout(model, 0.5)
+        model.train()
+        l_t, g_t = grads(0, 4)
+        assert l_t == l_t and abs(l_t) < 1e12 and len(g_t) == len(g_all)
+        assert all(bool(torch.isfinite(g).all()) for g in g_t.values())
+    finally:
+        ops.set_precision("f32")
