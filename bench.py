@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
-    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3"], default=os.environ.get("GLF_PRECISION", "f16x3"),
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
                          "passes the same parity gates), f16x3 = amax-scaled split-fp16 (three fp16 MFMAs per product, same gates; "
                          "default) or f32 = exact v_mfma_f32_32x32x2_f32")
@@ -270,13 +270,13 @@ def main():
         all_secs = sum(a[0] for a in agg.values())
         all_dense = sum(a[1] for a in agg.values())
         all_kept = sum(a[2] for a in agg.values())
-        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3}[precision]
+        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3, "f16": 1}[precision]
         # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
         # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
         #         16-bit FLOPs / time against the dense 16-bit MFMA peak (f16x3: THREE fp16 MFMA FLOPs per algorithmic FLOP)
         if precision != "f32":
             achieved, peak = nmul * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
-            fam = "bf16s" if precision == "bf16x6" else "f16s"
+            fam = "bf16s" if precision == "bf16x6" else "f16s"        # (f16 runs the f16s kernels with one product)
             kname = name.replace("gemm_rows_kernel<0,", f"gemm_rows_{fam}8_kernel<").replace("gemm_tn_kernel<", f"gemm_tn_{fam}8_kernel<")
         else:
             achieved, peak, kname = dense / secs / 1e12, FP32_MFMA_PEAK_TFLOPS, name
@@ -287,7 +287,8 @@ def main():
             "algorithmic_flops_per_launch": round((dense if precision == "f32" else nmul * kept) / launches),
             "arithmetic": {"f32": "v_mfma_f32_32x32x2_f32 (exact fp32)",
                            "bf16x6": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate",
-                           "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate"}[precision],
+                           "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate",
+                           "f16": "1 x v_mfma_f32_32x32x16_f16 per product (amax-scaled fp16 operands), fp32 accumulate"}[precision],
             "launches_per_step": launches // psteps, "avg_launch_ms": round(secs / launches * 1e3, 4),
             "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
             "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2),
@@ -337,7 +338,9 @@ def main():
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
-                      "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)"}[args.precision], "data": "synthetic",
+                      "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)",
+                      "f16": "f16 operands (amax-scaled, one MFMA per product), fp32 accumulate, fp32 storage: NOT fp32-equivalent "
+                             "(BASELINE.json configs[2], the 16-bit configuration)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
                        "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU",
@@ -349,7 +352,10 @@ def main():
                          "f16x3": "fp32 operands and results; each product = 3 fp16 MFMAs on an amax-scaled 2-way split (22 bits), fp32 "
                                   "accumulate; K=2048 GEMM error vs fp64 7e-7 (exact fp32 kernel 3e-7); every parity gate of tests/ "
                                   "(masks / Dice within 1e-4 of the fp32 reference, gradients within its fp32-vs-fp64 noise) passes "
-                                  "under this mode; the exact-fp32 step is reported as exact_f32"}[args.precision],
+                                  "under this mode; the exact-fp32 step is reported as exact_f32",
+                         "f16": "fp32 tensors in HBM; every contraction operand is rounded to fp16 (11 bits) after a per-tensor power-of-two "
+                                "scale, one MFMA per product, fp32 accumulate; parity is judged at the looser tolerance written in "
+                                "tests/test_gpu_model.py::test_f16_mode_parity, never as the fp32 headline"}[args.precision],
             "loss": main_leg["loss"], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
             "roofline": roofline_of(main_leg),
         }

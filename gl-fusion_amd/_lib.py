@@ -32,8 +32,15 @@ class GemmParams(C.Structure):
         ("alpha", C.c_float), ("accumulate", C.c_int32), ("split", C.c_int32), ("rect", C.c_int32),
         ("amax_a", C.c_void_p), ("amax_b", C.c_void_p), ("amax_c", C.c_void_p),
         ("colstats", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("precision", C.c_int32),
     ]
+
+
+class AttnParams(C.Structure):
+    """Mirror of glf_attn_params (include/glfusion.h)."""
+    _fields_ = [("frames", C.c_int32), ("L", C.c_int32), ("ci", C.c_int32),
+                ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldy", C.c_int64), ("lddy", C.c_int64), ("ldd", C.c_int64)]
 
 
 _SCALARS = {
@@ -48,6 +55,8 @@ def _ctype(decl: str):
         return None
     if "glf_gemm_params" in decl:
         return C.POINTER(GemmParams)
+    if "glf_attn_params" in decl:
+        return C.POINTER(AttnParams)
     if "*" in decl:
         return C.c_void_p
     t = decl.replace("const", "").split()

@@ -213,3 +213,12 @@ extern "C" int glf_scale(const float* x, float* y, int64_t numel, float scale, c
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, glf::S(s), x, y, (long long)numel, scale, scale_dev);
     return glf::check_launch("scale");
 }
+
+extern "C" int glf_zero(void* p, int64_t bytes, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(p != nullptr && bytes >= 0, GLF_ERR_NULL, "zero: null pointer / negative size");
+    if (bytes == 0) return GLF_OK;
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, glf::S(s));
+    if (e != hipSuccess) return glf::fail(GLF_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return GLF_OK;
+}

@@ -363,7 +363,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_bf16s_kernel(const GemmAr
     const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
-    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    // two-stage split-K: with a partial-sum workspace every (batch, slice, tap) block row stores its own [M][N] slab
+    // (plain stores, no atomics, no zero fill); tn_reduce_kernel sums the slabs in a fixed order
+    float* __restrict__ C = args.partial ? args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN)
+                                         : p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    const int ldc_e = args.partial ? pN : p_ldc;
 
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
     if (p_rect) {
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_bf16s_kernel(const GemmAr
         __syncthreads();
     }
 
-    const bool atomic = (p_split > 1) || p_accumulate;
+    const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_bf16s_kernel(const GemmAr
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
             if (row < pM) {
-                float* dst = C + (long long)row * p_ldc + col;
+                float* dst = C + (long long)row * ldc_e + col;
                 const float v = p_alpha * acc[r];
                 if (atomic) atomicAdd(dst, v); else *dst = v;
             }

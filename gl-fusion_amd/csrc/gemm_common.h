@@ -22,19 +22,20 @@ struct GemmArgs {
     const float* zeros;                         // f16x3 only: device page of ZERO_PAGE_FLOATS zeros
     float* amax_c;                              // f16x3 only: receives max(*amax_c, max|C written|) (null = not wanted)
     double* colstats;                           // f16x3 NT only: [2][N] += column sums of C and of C^2 (null = not wanted)
+    float* partial;                             // TN only: partial-sum slabs [batch*split][kept taps][M][N] (null = atomics into C)
 };
 constexpr int ZERO_PAGE_FLOATS = 1 << 18;
 
 
-int precision();                               // 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x6), 2 = split-fp16 (f16x3); glf_api.hip
+int precision();                               // 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x6), 2 = split-fp16 (f16x3), 3 = fp16 (one MFMA per product); glf_api.hip
 int init_gemm_bf16s_attrs();                   // gemm_bf16s.hip
 bool bf16s_rows_ok(const GemmArgs& a);
 bool bf16s_tn_ok(const GemmArgs& a);
 int launch_rows_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int launch_tn_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int init_gemm_f16s_attrs();                    // gemm_f16s.hip
-int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
-int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
+int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);   // nprod: 3 = f16x3, 1 = f16
+int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);
 int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s);
 float* amax_scratch(int n, hipStream_t s);     // n consecutive device floats from the ring of stream s (glf_api.hip)
 const float* zero_page();                      // ZERO_PAGE_FLOATS zeros on the device (glf_api.hip)
@@ -155,7 +156,7 @@ int validate(const glf_gemm_params* p, const void* A, const void* B, const void*
     GLF_REQUIRE(p->taps >= 1 && p->taps <= 32, GLF_ERR_BAD_SHAPE, "gemm: taps must be in [1,32] (got %d)", p->taps);
     GLF_REQUIRE(p->batch >= 1 && p->batch <= 65535, GLF_ERR_BAD_SHAPE, "gemm: batch out of range (%d)", p->batch);
     GLF_REQUIRE(p->gather >= 0 && p->gather <= 2, GLF_ERR_BAD_SHAPE, "gemm: gather must be 0,1,2");
-    GLF_REQUIRE(p->precision >= 0 && p->precision <= 3, GLF_ERR_UNSUPPORTED, "gemm: precision must be 0 (process default), 1 (fp32), 2 (bf16x6) or 3 (f16x3)");
+    GLF_REQUIRE(p->precision >= 0 && p->precision <= 4, GLF_ERR_UNSUPPORTED, "gemm: precision must be 0 (process default), 1 (fp32), 2 (bf16x6), 3 (f16x3) or 4 (f16)");
     const unsigned full = p->taps == 32 ? 0xffffffffu : ((1u << p->taps) - 1u);
     GLF_REQUIRE((p->tap_mask & ~full) == 0, GLF_ERR_BAD_SHAPE, "gemm: tap_mask has bits beyond taps");
     if (p->gather) {
@@ -178,7 +179,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
-    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr;
     return a;
 }
 
@@ -204,7 +205,7 @@ int setup_rect(const glf_gemm_params* p, const float* bias, GemmArgs& a, dim3& g
 
 // contraction precision of this call: glf_gemm_params.precision (1 + mode) or, when 0, the process default
 inline int call_precision(const glf_gemm_params* p) {
-    return (p->precision >= 1 && p->precision <= 3) ? p->precision - 1 : glf::precision();
+    return (p->precision >= 1 && p->precision <= 4) ? p->precision - 1 : glf::precision();
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

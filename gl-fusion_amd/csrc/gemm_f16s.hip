@@ -61,13 +61,17 @@ __device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& i
 #define GLF_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 // one A tile-row against both B tile-cols for one 16-deep k-step: main products into c, mixed products into m
 // (dependent MFMAs are two apart)
+// NP (a compile-time constant of the enclosing kernel) = MFMAs per product: 3 = split-fp16 (fp32-grade results),
+// 1 = the high halves only (precision 3, "f16": plain fp16 operands with an amax scale, fp32 accumulate)
 #define GLF_ROW3(c0, c1, m0, m1, ah, al, b0h, b0l, b1h, b1l)  \
     c0 = GLF_MFMA_F16(ah, b0h, c0);                         \
     c1 = GLF_MFMA_F16(ah, b1h, c1);                         \
-    m0 = GLF_MFMA_F16(al, b0h, m0);                         \
-    m1 = GLF_MFMA_F16(al, b1h, m1);                         \
-    m0 = GLF_MFMA_F16(ah, b0l, m0);                         \
-    m1 = GLF_MFMA_F16(ah, b1l, m1);
+    if (NP == 3) {                                          \
+        m0 = GLF_MFMA_F16(al, b0h, m0);                     \
+        m1 = GLF_MFMA_F16(al, b1h, m1);                     \
+        m0 = GLF_MFMA_F16(ah, b0l, m0);                     \
+        m1 = GLF_MFMA_F16(ah, b1l, m1);                     \
+    }
 
 // ----------------------------------------------------------------------------------------------------------
 // rows kernel, NT.  512 threads = 8 waves (4 x 2), tile 256 x 128 x 32, THREE LDS buffers of 2 x (256 + 128) rows
@@ -79,7 +83,7 @@ constexpr int PL_A8 = BM8 * 64, PL_B8 = BN * 64;
 constexpr int BUF8 = 2 * PL_A8 + 2 * PL_B8;
 constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 
-template <bool GATHER>
+template <bool GATHER, int NP>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -221,13 +225,13 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     {                                                                                                        \
         const SplitH s = split4h(ra[J], sc_a);                                                               \
         unsigned char* d = smem_s + (buf_) * BUF8 + st_off + J * 64 * 64;                                    \
-        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;                      \
+        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;         \
     }
 #define GLF_H8_CONV_B(J, buf_)                                                                               \
     {                                                                                                        \
         const SplitH s = split4h(rb[J], sc_b);                                                               \
         unsigned char* d = smem_s + (buf_) * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64;                        \
-        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;                      \
+        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;         \
     }
     // piece pc (0..5): convert + store registers of tile t+1, then refill them with tile t+2
 #define GLF_H8_PIECE(pc, buf_, conv_, load_)                                                                 \
@@ -272,11 +276,13 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             P##b0h = *reinterpret_cast<const f16x8*>(bb_);                                                    \
             P##b1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                          \
             P##a0h = *reinterpret_cast<const f16x8*>(ab_);                                                    \
-            P##a0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                            \
-            P##b0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                            \
-            P##b1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                                  \
             P##a1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                          \
-            P##a1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                                  \
+            if (NP == 3) {                                                                                    \
+                P##a0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                        \
+                P##b0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                        \
+                P##b1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                              \
+                P##a1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                              \
+            } else { P##a0l = P##a0h; P##b0l = P##b0h; P##b1l = P##b1h; P##a1l = P##a1h; }                    \
         }
         GLF_H8_FRAGS(f, 0, fo0)
         int cur = 0, nxt = 1, wr = 2;           // LDS buffers of tile it, it+1, it+2
@@ -381,7 +387,7 @@ constexpr int PLANE_T = 32 * RST;
 constexpr int OPER_T = 2 * PLANE_T;
 constexpr size_t SMEM_TN_H = 2 * OPER_T + 32 * sizeof(int);
 
-template <bool GATHER>
+template <bool GATHER, int NP>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_accumulate = args.accumulate, p_split = args.split;
@@ -417,7 +423,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
-    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    // two-stage split-K: with a partial-sum workspace every (batch, slice, tap) block row stores its own [M][N] slab
+    // (plain stores, no atomics, no zero fill); tn_reduce_kernel sums the slabs in a fixed order
+    float* __restrict__ C = args.partial ? args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN)
+                                         : p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    const int ldc_e = args.partial ? pN : p_ldc;
 
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
     if (p_rect) {
@@ -474,8 +484,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
         const SplitH sb = split4h(rb[J], sc_b);                                                            \
         unsigned char* da = As + (rr + 8 * J) * RST + c4 * 8;                                              \
         unsigned char* db = Bs + (rr + 8 * J) * RST + c4 * 8;                                              \
-        *reinterpret_cast<f16x4*>(da) = sa.h; *reinterpret_cast<f16x4*>(da + PLANE_T) = sa.l;              \
-        *reinterpret_cast<f16x4*>(db) = sb.h; *reinterpret_cast<f16x4*>(db + PLANE_T) = sb.l;              \
+        *reinterpret_cast<f16x4*>(da) = sa.h; if (NP == 3) *reinterpret_cast<f16x4*>(da + PLANE_T) = sa.l; \
+        *reinterpret_cast<f16x4*>(db) = sb.h; if (NP == 3) *reinterpret_cast<f16x4*>(db + PLANE_T) = sb.l; \
         if (c4 == 0) vflag[rr + 8 * J] = rvalid[J];                                                        \
     }
 
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
         __syncthreads();
     }
 
-    const bool atomic = (p_split > 1) || p_accumulate;
+    const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
             if (row < pM) {
-                float* dst = C + (long long)row * p_ldc + col;
+                float* dst = C + (long long)row * ldc_e + col;
                 const float v = p_alpha * acc[r];
                 if (atomic) atomicAdd(dst, v); else { *dst = v; cmax = fmaxf(cmax, fabsf(v)); }
             }
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
-    if (args.amax_c && !atomic) {
+    if (args.amax_c && !atomic && !args.partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
@@ -560,7 +570,7 @@ constexpr int PA8 = 32 * RSA, PB8 = 32 * RSB;
 constexpr int TBUF8 = 2 * PA8 + 2 * PB8;
 constexpr size_t SMEM_TN_H8 = 2 * TBUF8;
 
-template <bool GATHER>
+template <bool GATHER, int NP>
 __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_accumulate = args.accumulate, p_split = args.split;
@@ -593,7 +603,11 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
-    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    // two-stage split-K: with a partial-sum workspace every (batch, slice, tap) block row stores its own [M][N] slab
+    // (plain stores, no atomics, no zero fill); tn_reduce_kernel sums the slabs in a fixed order
+    float* __restrict__ C = args.partial ? args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN)
+                                         : p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    const int ldc_e = args.partial ? pN : p_ldc;
 
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
     if (p_rect) {
@@ -688,13 +702,13 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     {                                                                                                        \
         const SplitH s = split4h(ra[J], sc_a);                                                               \
         unsigned char* d = smem_s + (buf_) * TBUF8 + st_a + J * 8 * RSA;                                     \
-        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PA8) = s.l;                        \
+        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PA8) = s.l;           \
     }
 #define GLF_T8_CONV_B(J, buf_)                                                                               \
     {                                                                                                        \
         const SplitH s = split4h(rb[J], sc_b);                                                               \
         unsigned char* d = smem_s + (buf_) * TBUF8 + 2 * PA8 + st_b + J * 16 * RSB;                          \
-        *reinterpret_cast<f16x4*>(d) = s.h; *reinterpret_cast<f16x4*>(d + PB8) = s.l;                        \
+        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PB8) = s.l;           \
     }
 #define GLF_T8_PIECE(pc, buf_, conv_, load_)                                                                 \
     switch (pc) {                                                                                            \
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     if (it + 1 < ntiles) { GLF_T8_BODY(true, false) ++it; }
     GLF_T8_BODY(false, false)
 
-    const bool atomic = (p_split > 1) || p_accumulate;
+    const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         for (int r = 0; r < 16; ++r) {
             const int row = tm * TM8 + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
             if (row < pM) {
-                float* dst = C + (long long)row * p_ldc + col;
+                float* dst = C + (long long)row * ldc_e + col;
                 const float v = p_alpha * acc[r];
                 if (atomic) atomicAdd(dst, v); else { *dst = v; cmax = fmaxf(cmax, fabsf(v)); }
             }
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     };
     emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
     emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
-    if (args.amax_c && !atomic) {
+    if (args.amax_c && !atomic && !args.partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
@@ -826,12 +840,18 @@ int init_gemm_f16s_attrs() {
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-    SET_ATTR((gemm_rows_f16s8_kernel<false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_tn_f16s_kernel<false>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s_kernel<true>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s8_kernel<false>), SMEM_TN_H8)
-    SET_ATTR((gemm_tn_f16s8_kernel<true>), SMEM_TN_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_tn_f16s_kernel<false, 3>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s_kernel<true, 3>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s8_kernel<false, 3>), SMEM_TN_H8)
+    SET_ATTR((gemm_tn_f16s8_kernel<true, 3>), SMEM_TN_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_tn_f16s_kernel<false, 1>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s_kernel<true, 1>), SMEM_TN_H)
+    SET_ATTR((gemm_tn_f16s8_kernel<false, 1>), SMEM_TN_H8)
+    SET_ATTR((gemm_tn_f16s8_kernel<true, 1>), SMEM_TN_H8)
 #undef SET_ATTR
     return GLF_OK;
 }
@@ -845,7 +865,7 @@ bool f16s_tn_ok(const GemmArgs& a) {
            a.M <= ZERO_PAGE_FLOATS && a.N <= ZERO_PAGE_FLOATS && zero_page() != nullptr;
 }
 
-int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) {
+int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
     GemmArgs a = a0;
     a.zeros = zero_page();
     long long tiles_m = (a.M + BM8 - 1) / BM8;
@@ -868,23 +888,38 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) 
     }
     a.tiles_m = (int)tiles_m;
     dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
-    if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-    else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    if (nprod == 3) {
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    } else {
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 1>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 1>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    }
     return check_launch("gemm_nt(f16x3, 256x128)");
 }
 
-int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, hipStream_t s) {
+int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
     GemmArgs a = a0;
     a.zeros = zero_page();
     if (a.M > BM) {                     // 256-wide tiles: re-derive the grid
         a.tiles_m = (a.M + TM8 - 1) / TM8;
         dim3 g2((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
-        if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true>), g2, dim3(NT8), SMEM_TN_H8, s, a);
-        else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+        if (nprod == 3) {
+            if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true, 3>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+            else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false, 3>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+        } else {
+            if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true, 1>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+            else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false, 1>), g2, dim3(NT8), SMEM_TN_H8, s, a);
+        }
         return check_launch("gemm_tn(f16x3, 256x128)");
     }
-    if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
-    else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+    if (nprod == 3) {
+        if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true, 3>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+        else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false, 3>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+    } else {
+        if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true, 1>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+        else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false, 1>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
+    }
     return check_launch("gemm_tn(f16x3)");
 }
 

@@ -432,7 +432,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
     const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
-    float* __restrict__ C = p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    // two-stage split-K: with a partial-sum workspace every (batch, slice, tap) block row stores its own [M][N] slab
+    // (plain stores, no atomics, no zero fill); tn_reduce_kernel sums the slabs in a fixed order
+    float* __restrict__ C = args.partial ? args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN)
+                                         : p_C + (long long)bz * p_bsc + (long long)tap * p_tsb;
+    const int ldc_e = args.partial ? pN : p_ldc;
 
     // rect mode: the reduction runs over this tap's rectangle of output pixels only (see tap_rect)
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd, pKe = pK;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
         __syncthreads();
     }
 
-    const bool atomic = (p_split > 1) || p_accumulate;
+    const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     auto emit = [&](const f32x16& acc, int ti, int tj) {
         const int col = tn * BN + wn + 32 * tj + col_l;
@@ -563,13 +567,71 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
         for (int r = 0; r < 16; ++r) {
             const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
             if (row < pM) {
-                float* dst = C + (long long)row * p_ldc + col;
+                float* dst = C + (long long)row * ldc_e + col;
                 const float v = p_alpha * acc[r];
                 if (atomic) atomicAdd(dst, v); else *dst = v;
             }
         }
     };
     emit(c00, 0, 0); emit(c01, 0, 1); emit(c10, 1, 0); emit(c11, 1, 1);
+}
+
+// ----------------------------------------------------------------------------------------
+// second stage of the two-stage split-K reduction of glf_gemm_tn: C_tap = (accumulate ? C_tap : 0) + sum over the valid
+// slices of their partial slabs, in slice order (bitwise reproducible).  grid: x over M*N, y = kept-tap ordinal, z = batch.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ Cb, int M, int N, int ldc,
+                                                        long long tsb, long long bsc, int split, unsigned tap_mask, int accumulate,
+                                                        int K, int rect, Geo g, int vec, float* __restrict__ amax_c) {
+    unsigned mm = tap_mask;
+    for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
+    const int tap = __ffs(mm) - 1;
+    const int ntap = gridDim.y, bz = blockIdx.z;
+    int pKe = K;
+    if (rect) {
+        int y0, y1, x0, x1;
+        tap_rect(1, tap, g.kw, g.pad, g.dil, g.hs, g.ws, g.hd, g.wd, y0, y1, x0, x1);
+        pKe = g.n_img * (y1 - y0) * (x1 - x0);
+    }
+    int chunk = (pKe + split - 1) / split;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    const int nvalid = chunk > 0 ? min(split, (pKe + chunk - 1) / chunk) : 0;       // slices that ran (the others returned early)
+    const long long mn = (long long)M * N;
+    const float* __restrict__ src = partial + ((long long)bz * split * ntap + blockIdx.y) * mn;
+    const long long slice_stride = (long long)ntap * mn;
+    float* __restrict__ C = Cb + (long long)bz * bsc + (long long)tap * tsb;
+    float cmax = 0.f;
+    if (vec) {
+        const int n4 = N >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)M * n4; i += (long long)gridDim.x * blockDim.x) {
+            const long long row = i / n4;
+            const int c4 = (int)(i - row * n4) * 4;
+            float* dst = C + row * ldc + c4;
+            float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* sp = src + row * N + c4;
+            for (int sl = 0; sl < nvalid; ++sl) {
+                const float4 v = *reinterpret_cast<const float4*>(sp + sl * slice_stride);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(dst) = acc;
+            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long long)gridDim.x * blockDim.x) {
+            const long long row = i / N;
+            const int col = (int)(i - row * N);
+            float* dst = C + row * ldc + col;
+            float acc = accumulate ? *dst : 0.f;
+            for (int sl = 0; sl < nvalid; ++sl) acc += src[sl * slice_stride + i];
+            *dst = acc;
+            cmax = fmaxf(cmax, fabsf(acc));
+        }
+    }
+    if (amax_c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_c), __float_as_uint(cmax));
+    }
 }
 
 constexpr size_t SMEM_ROWS_NT = (2 * BK * LD_T + 2 * BK * LD_T) * sizeof(float) + 16;
@@ -651,7 +713,7 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
     if (p->rect == 2) {                 // region mode: f16x3 kernels only (see region_of in gemm_common.h)
-        GLF_REQUIRE(prec == 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
+        GLF_REQUIRE(prec >= 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
                     "glf_gemm_nt: rect = 2 (region mode) exists on the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands)");
         GLF_REQUIRE(p->gather != 0 && p->kh == 3 && p->kw == 3 && p->stride == 1 && p->pad == p->dil && p->hs == p->hd && p->ws == p->wd &&
                     p->batch == 1, GLF_ERR_UNSUPPORTED, "glf_gemm_nt: region mode needs a 3x3 stride-1 conv with pad == dil on equal maps, batch 1");
@@ -659,12 +721,12 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     } else if (p->rect) {
         if (int rc = setup_rect(p, bias, a, grid, "glf_gemm_nt")) return rc;
     }
-    GLF_REQUIRE(!p->colstats || (prec == 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
+    GLF_REQUIRE(!p->colstats || (prec >= 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
                 "glf_gemm_nt: colstats is honoured by the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands, no rect = 1, batch 1)");
     if (prec == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
-    if (prec == 2 && glf::f16s_rows_ok(a)) {
+    if (prec >= 2 && glf::f16s_rows_ok(a)) {
         if (int rc = self_amax(a, p, false, glf::S(stream))) return rc;
-        return glf::launch_rows_f16s(a, grid, p->gather != 0, glf::S(stream));
+        return glf::launch_rows_f16s(a, grid, p->gather != 0, prec == 2 ? 3 : 1, glf::S(stream));
     }
     if (p->gather)
         hipLaunchKernelGGL((gemm_rows_kernel<0, true>), grid, dim3(NTHREADS), SMEM_ROWS_NT, glf::S(stream), a);
@@ -717,15 +779,41 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
     }
     dim3 grid(a.tiles_m * a.tiles_n, ntap, p->batch * a.split);
     const int prec = call_precision(p);
-    if (prec == 1 && glf::bf16s_tn_ok(a)) return glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
-    if (prec == 2 && glf::f16s_tn_ok(a)) {
-        if (int rc = self_amax(a, p, true, glf::S(stream))) return rc;
-        return glf::launch_tn_f16s(a, grid, p->gather != 0, glf::S(stream));
+    const bool two_stage = a.split > 1 && p->workspace != nullptr;
+    if (two_stage) {
+        GLF_REQUIRE(p->workspace_bytes >= (int64_t)glf_gemm_tn_workspace_bytes(p), GLF_ERR_WORKSPACE,
+                    "gemm_tn: workspace of %lld bytes, glf_gemm_tn_workspace_bytes() asks for %zu", (long long)p->workspace_bytes,
+                    glf_gemm_tn_workspace_bytes(p));
+        GLF_REQUIRE(aligned16(p->workspace), GLF_ERR_WORKSPACE, "gemm_tn: workspace must be 16-byte aligned");
+        a.partial = p->workspace;
     }
-    if (p->gather)
-        hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
-    return glf::check_launch("gemm_tn");
+    int rc;
+    if (prec == 1 && glf::bf16s_tn_ok(a)) {
+        rc = glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));
+    } else if (prec >= 2 && glf::f16s_tn_ok(a)) {
+        if (int rc2 = self_amax(a, p, true, glf::S(stream))) return rc2;
+        rc = glf::launch_tn_f16s(a, grid, p->gather != 0, prec == 2 ? 3 : 1, glf::S(stream));
+    } else {
+        if (p->gather)
+            hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(NTHREADS), SMEM_TN, glf::S(stream), a);
+        rc = glf::check_launch("gemm_tn");
+    }
+    if (rc != GLF_OK || !two_stage) return rc;
+    const int vec = (p->N % 4 == 0) && (p->ldc % 4 == 0) && aligned16(C) && (p->tap_stride_b % 4 == 0) && (p->batch_stride_c % 4 == 0);
+    const long long work = vec ? (long long)p->M * (p->N / 4) : (long long)p->M * p->N;
+    long long bx = (work + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)bx, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, p->M, p->N, p->ldc,
+                       (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->accumulate, p->K, a.rect, a.g, vec,
+                       p->amax_c);
+    return glf::check_launch("gemm_tn(reduce)");
+}
+
+extern "C" size_t glf_gemm_tn_workspace_bytes(const glf_gemm_params* p) {
+    if (!p || p->split <= 1) return 0;
+    const size_t ntap = (size_t)__builtin_popcount(p->tap_mask);
+    return (size_t)p->batch * (size_t)p->split * ntap * (size_t)p->M * (size_t)p->N * sizeof(float);
 }
 

@@ -7,6 +7,7 @@
 namespace glf {
 
 int init_gemm_attrs();   // gemm_f32.hip
+int init_attn_attrs();   // attn_softmax.hip
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -92,6 +93,7 @@ int ensure_init() {
         if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
         st.cus = prop.multiProcessorCount;
         if (int rc = init_gemm_attrs()) return rc;           // hipFuncSetAttribute is per device
+        if (int rc = init_attn_attrs()) return rc;
         e = hipMalloc(reinterpret_cast<void**>(&st.zeros), ZERO_PAGE_FLOATS * sizeof(float));
         if (e == hipSuccess) e = hipMemset(st.zeros, 0, ZERO_PAGE_FLOATS * sizeof(float));
         if (e != hipSuccess) return fail(GLF_ERR_WORKSPACE, "hipMalloc(zero page): %s", hipGetErrorString(e));
@@ -104,11 +106,11 @@ int ensure_init() {
 }  // namespace glf
 
 extern "C" const char* glf_last_error(void) { return glf::err_buf(); }
-extern "C" int glf_abi_version(void) { return 3; }
+extern "C" int glf_abi_version(void) { return 4; }
 extern "C" int glf_init(void) { return glf::ensure_init(); }
 extern "C" size_t glf_sizeof_gemm_params(void) { return sizeof(glf_gemm_params); }
 extern "C" int glf_set_precision(int mode) {
-    if (mode < 0 || mode > 2) return glf::fail(GLF_ERR_UNSUPPORTED, "glf_set_precision: mode must be 0 (fp32 MFMA), 1 (split-bf16 x6) or 2 (split-fp16 x3)");
+    if (mode < 0 || mode > 3) return glf::fail(GLF_ERR_UNSUPPORTED, "glf_set_precision: mode must be 0 (fp32 MFMA), 1 (split-bf16 x6), 2 (split-fp16 x3) or 3 (fp16 x1)");
     glf::g_precision.store(mode);
     return GLF_OK;
 }

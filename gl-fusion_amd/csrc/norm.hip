@@ -195,6 +195,21 @@ __global__ __launch_bounds__(256) void sum_finalize(const double* __restrict__ p
     if (out_b) out_b[ch] = (float)q;
 }
 
+// running-statistics update of a train-mode BatchNorm replayed from its saved batch statistics (mean, invstd): what a second
+// forward over the same input would have done to running_mean / running_var / num_batches_tracked
+__global__ void bn_replay_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, int rows, float eps, float momentum,
+                                 float* rmean, float* rvar, long long* nbt, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) *nbt += 1;
+    if (ch >= c) return;
+    const double is = (double)invstd[ch];
+    double var = 1.0 / (is * is) - (double)eps;
+    if (var < 0) var = 0;
+    const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+    rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean[ch];
+    rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, float eps, float* mean, float* invstd, int c) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
@@ -434,6 +449,16 @@ extern "C" int glf_bn_stats_from_sums(const double* sums, int rows, int c, float
     hipLaunchKernelGGL(bn_stats_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), sums, 1, c, rows,
                        eps, momentum, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
     return glf::check_launch("bn_stats_from_sums");
+}
+
+extern "C" int glf_bn_replay_running(const float* mean, const float* invstd, int rows, int c, float eps, float momentum,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(mean && invstd && running_mean && running_var, GLF_ERR_NULL, "bn_replay_running: null argument");
+    GLF_REQUIRE(rows > 0 && c > 0, GLF_ERR_BAD_SHAPE, "bn_replay_running: rows and c must be > 0");
+    hipLaunchKernelGGL(bn_replay_kernel, dim3((c + 255) / 256), dim3(256), 0, glf::S(s), mean, invstd, rows, eps, momentum,
+                       running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), c);
+    return glf::check_launch("bn_replay_running");
 }
 
 extern "C" int glf_bn_eval_coeffs(const float* rm, const float* rv, float eps, float* mean, float* invstd, int c, glf_stream_t s) {

@@ -15,13 +15,61 @@ Tail (ours.py:908-915): w = W_z y + b;  z = LayerNorm_C( BatchNorm3d(w) + x ) in
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import weakref
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import check, lib
+from ._lib import AttnParams, check, lib
 from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
-                  transpose2d, weight_T)
+                  tn_needs_zero, transpose2d, weight_T, zeros)
+
+
+FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
+
+
+def fused_softmax_ok(ci: int) -> bool:
+    """The fused QK^T / softmax / PV kernel covers Ci % 32 == 0, Ci <= 1024 (the model: Ci = 1024); other widths (toy
+    modules) materialise the scores per frame."""
+    return FUSED_SOFTMAX and ci % 32 == 0 and ci <= 1024
+
+
+def _attn_params(n: int, L: int, ci: int, ldqkv: int, ldy: int) -> AttnParams:
+    ap = AttnParams()
+    ap.frames, ap.L, ap.ci = n, L, ci
+    ap.ldq = ap.ldk = ap.ldv = ldqkv
+    ap.ldy, ap.lddy, ap.ldd = ldy, ldy, ldqkv
+    return ap
+
+
+_qkv_cache = {}
+
+
+def _qkv_weights(params):
+    """theta | phi | g weights stacked as ONE [3*ci, c] operand (+ the stacked bias), so the three projections run as a
+    single contraction over the shared input.  Rebuilt (three strided copies by glf_copy_frames, no torch.cat) only when one
+    of the six parameters changed: cached against their version counters, like the conv weight re-layouts in ops.py."""
+    th_w, ph_w, g_w, th_b, ph_b, g_b = params
+    key = id(th_w)
+    sig = tuple((id(t), t._version, t.data_ptr()) for t in params)
+    hit = _qkv_cache.get(key)
+    if hit is not None and hit[0]() is th_w and hit[1] == sig:
+        return hit[2], hit[3]
+    ci, c = th_w.shape[0], th_w.shape[1]
+    if ci % 4 == 0:
+        Wcat = torch.empty(3 * ci, c, dtype=torch.float32, device=th_w.device)
+        bcat = torch.empty(3 * ci, dtype=torch.float32, device=th_w.device)
+        for i, (w, b) in enumerate(((th_w, th_b), (ph_w, ph_b), (g_w, g_b))):
+            check(lib.glf_copy_frames(_p(_contig(w.detach())), ci * c, _p(Wcat[i * ci:]), ci * c, 1, ci * c, _stream()), "qkv_weights")
+            check(lib.glf_copy_frames(_p(_contig(b.detach())), ci, _p(bcat[i * ci:]), ci, 1, ci, _stream()), "qkv_bias")
+    else:                                              # odd toy widths only (the 16-byte copy kernel does not apply)
+        Wcat = torch.cat([_contig(t.detach()).view(ci, c) for t in (th_w, ph_w, g_w)], dim=0)
+        bcat = torch.cat((th_b.detach(), ph_b.detach(), g_b.detach()), dim=0)
+    _qkv_cache[key] = (weakref.ref(th_w, lambda _r, k=key: _qkv_cache.pop(k, None)), sig, Wcat, bcat)
+    return Wcat, bcat
 
 
 class TpaviFn(Function):
@@ -38,17 +86,17 @@ class TpaviFn(Function):
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
         W = lambda t: _contig(t.detach()).view(t.shape[0], t.shape[1])       # Conv3d 1x1x1 weight -> [out, in]
-        thW, phW, gW, zW = W(th_w), W(ph_w), W(g_w), W(wz_w)
+        zW = W(wz_w)
 
         # theta | phi | g in ONE contraction over the shared input: qkv[rows, 3*ci] (x is read once; the three
         # operands below are column slices with row stride 3*ci)
-        Wcat = torch.cat((thW, phW, gW), dim=0)                              # [3*ci, c]
-        bcat = torch.cat((th_b.detach(), ph_b.detach(), g_b.detach()), dim=0)
+        Wcat, bcat = _qkv_weights((th_w, ph_w, g_w, th_b, ph_b, g_b))         # [3*ci, c], [3*ci]
         c3 = 3 * ci
         qkv = torch.empty(rows, c3, **f32)
         am_x = amax_of(x)
         am_q = amax_slot(dev)                # max|qkv| from the epilogue: one bound for the theta | phi | g column slices
         gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=amax_of(Wcat), amax_c=am_q)
+        ctx.qkv_owner = th_w                      # parameter the stacked operand (and its cached transpose) is keyed on
         set_amax(qkv, am_q)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
         bq = L * c3                                                          # batch (frame) stride inside qkv
@@ -69,8 +117,14 @@ class TpaviFn(Function):
                 del attT
             else:
                 gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
+        elif mode == "embedded" and fused_softmax_ok(ci):
+            # ONE kernel: 64-query blocks, key tiles through LDS, online row max / sum, P g in MFMA accumulators; the
+            # [L, L] scores are never written.  `att` holds the row log-sum-exp the backward pass recomputes them against.
+            att = torch.empty(n * L, **f32)
+            ap = _attn_params(n, L, ci, c3, ci)
+            check(lib.glf_attn_softmax_fwd(_p(th), _p(ph), _p(g), _p(y), _p(att), C.byref(ap), _stream()), "attn_softmax_fwd")
         elif mode == "embedded":
-            att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T)
+            att = torch.empty(n, L, L, **f32)                                # softmax(theta phi^T), materialised (odd widths only)
             gemm("nt", th, ph, att, M=L, N=L, K=ci, lda=c3, ldb=c3, ldc=L, batch=n, bsa=bq, bsb=bq, bsc=L * L,
                  amax_a=am_q, amax_b=am_q)
             check(lib.glf_softmax_rows(_p(att), n * L, L, _stream()), "softmax_rows")
@@ -127,7 +181,7 @@ class TpaviFn(Function):
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)
-        dzW = (torch.empty if sp == 1 else torch.zeros)(c, ci, **f32)
+        dzW = (zeros if tn_needs_zero(sp) else torch.empty)(c, ci, **f32)
         am_dwz, am_q = amax_of(dwz), amax_of(qkv)
         gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=amax_of(y))
         dzb = colsum(dwz, rows, c)
@@ -168,6 +222,14 @@ class TpaviFn(Function):
                 del dMT
             else:
                 gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+        elif fused_softmax_ok(ci):
+            # recompute the score tiles from theta / phi and the saved row log-sum-exp: three passes (dg, dphi, dtheta), each
+            # writing its slice of dqkv exactly once
+            ap = _attn_params(n, L, ci, c3, ci)
+            ap.lddy, ap.ldd = ci, c3
+            dsum = torch.empty(rows, **f32)
+            check(lib.glf_attn_softmax_bwd(_p(th), _p(ph), _p(g), _p(y), _p(dy), _p(att), _p(dth), _p(dph), _p(dg), _p(dsum), C.byref(ap),
+                                           _stream()), "attn_softmax_bwd")
         else:
             # y_n = P_n g_n ; P_n = softmax(th_n ph_n^T)
             dP = torch.empty(n, L, L, **f32)
@@ -184,7 +246,7 @@ class TpaviFn(Function):
 
         # the three projections as one: qkv = x Wcat^T + bcat
         sp = _tn_split(rows, c3, c, 1)
-        dWcat = (torch.empty if sp == 1 else torch.zeros)(c3, c, **f32)
+        dWcat = (zeros if tn_needs_zero(sp) else torch.empty)(c3, c, **f32)
         am_dq = amax_of(dqkv)
         gemm("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp, amax_a=am_dq, amax_b=amax_of(x))
         dbcat = colsum(dqkv, rows, c3)
@@ -192,7 +254,7 @@ class TpaviFn(Function):
         grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
         dx = du                                              # residual gradient, accumulated in place (one RMW)
         if split:
-            WcatT = transpose2d(Wcat, c3, c).view(c, c3)
+            WcatT = weight_T(Wcat, Wcat)                        # cached with the stacked operand (one rebuild per weight update)
             gemm("nt", dqkv, WcatT, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=amax_of(Wcat))
         else:
             gemm("nn", dqkv, Wcat, dx, M=rows, N=c, K=c3, lda=c3, ldb=c, ldc=c, accumulate=True)

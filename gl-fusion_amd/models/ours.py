@@ -326,3 +326,140 @@ class Local_only(_PerViewNetworks):
             atten[v] = secs[i][2]
             mask[v], mask_bb[v] = heads[i]
         return mask, mask_bb, atten, f4_l
+
+
+class model19(nn.Module):
+    """ours.py:976-1041: per-view encoders and classifier heads (no centre-ness heads, no gate) around ONE fusion block
+    registered as `non_local`; returns (mask, mask_bb, f4, f4_fusion)."""
+
+    def __init__(self, view_num: Sequence[str], local_attn: bool = False, test_view: Sequence[str] = ("1", "2", "3", "4")) -> None:
+        super().__init__()
+        self.outchannel_list = {"1": 2, "2": 1, "3": 2, "4": 4}
+        self.view_num, self.test_view, self.local_attn = view_num, test_view, local_attn
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)
+        self.init_block = nn.ModuleDict()
+        self.layer1 = nn.ModuleDict()
+        self.layer2 = nn.ModuleDict()
+        self.layer3 = nn.ModuleDict()
+        self.layer4 = nn.ModuleDict()
+        self.classifier = nn.ModuleDict()
+        bb = self.network.backbone
+        for view in self.view_num:                                       # ours.py:990-1006
+            self.init_block[view] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            self.layer1[view] = copy.deepcopy(bb["layer1"])
+            self.layer2[view] = copy.deepcopy(bb["layer2"])
+            self.layer3[view] = copy.deepcopy(bb["layer3"])
+            self.layer4[view] = copy.deepcopy(bb["layer4"])
+            self.classifier[view] = copy.deepcopy(self.network.classifier)
+            last = self.network.classifier[-1]
+            self.classifier[view][-1] = Conv2d(last.in_channels, 5, kernel_size=last.kernel_size)
+        self.non_local = TPAVIModule(in_channels=2048, mode="dot")      # ours.py:1008
+
+    _encode_view = _PerViewNetworks._encode_view
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        views = list(self.view_num)
+        hw = x[views[0]].shape[-2:]
+        ho, wo = int(hw[0]), int(hw[1])
+        secs = ops.parallel_sections([lambda v=v: ops.fan_out(self._encode_view(v, x[v]), 3) for v in views])   # fusion / mask_bb / returned f4
+        out = self.non_local.forward_nvhwc(ops.stack_views([s[0] for s in secs]))                               # ours.py:1030-1033
+        per_view = ops.split_views(out)
+
+        def head_section(i, v):                                          # ours.py:1036-1041
+            m = ops.bilinear_up(self.classifier[v].forward_nhwc(per_view[i]), ho, wo)
+            mb = ops.bilinear_up(self.classifier[v].forward_nhwc(secs[i][1]), ho, wo)
+            return m, mb
+
+        heads = ops.parallel_sections([lambda i=i, v=v: head_section(i, v) for i, v in enumerate(views)])
+        mask, mask_bb, f4, f4_fusion = {}, {}, {}, {}
+        for i, v in enumerate(views):
+            mask[v], mask_bb[v] = heads[i]
+            f4[v] = ops.from_nhwc(secs[i][2])
+            f4_fusion[v] = out[:, i].permute(0, 3, 1, 2)
+            f4_fusion[v]._glf_stack = (out, i)
+        return mask, mask_bb, f4, f4_fusion
+
+
+class Global_and_Local_CPS(nn.Module):
+    """ours.py:3141-3349 (cross pseudo supervision): two Global_and_Local networks over the same input.  Network 1 owns
+    per-view deep copies of the template; network 2's encoders ARE the template's modules, shared by all views
+    (ours.py:3192-3202 registers them without deepcopy): `init_block_2.<v>.*` / `layer*_2.<v>.*` alias
+    `network.backbone.*` in the state_dict, gradients sum over the views, and the shared BatchNorm layers update their
+    running statistics once per view -- so network 2's encoders run view after view on one stream, in the reference's
+    order.  Neither network evaluates the backbone-only mask.  Returns (mask, mask_2, f4_global_fusion, f4_local_fusion)."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__()
+        self.outchannel_list = {"1": 2, "2": 1, "3": 2, "4": 4}
+        self.view_num, self.test_view, self.center_aware_weight = view_num, test_view, center_aware_weight
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)
+        for sfx in ("_1", "_2"):                                         # registration order of ours.py:3150-3165
+            for name in ("init_block", "layer1", "layer2", "layer3", "layer4", "classifier", "centerness"):
+                setattr(self, name + sfx, nn.ModuleDict())
+        bb = self.network.backbone
+        last = self.network.classifier[-1]
+        for view in self.view_num:                                       # ours.py:3167-3187
+            self.init_block_1[view] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            for l in ("layer1", "layer2", "layer3", "layer4"):
+                getattr(self, l + "_1")[view] = copy.deepcopy(bb[l])
+            self.classifier_1[view] = copy.deepcopy(self.network.classifier)
+            self.classifier_1[view][-1] = Conv2d(last.in_channels, 5, kernel_size=last.kernel_size)
+            self.centerness_1[view] = copy.deepcopy(self.network.classifier)
+            self.centerness_1[view][-1] = Conv2d(last.in_channels, 1, kernel_size=last.kernel_size)
+        self.global_attn_1 = TPAVIModule(in_channels=2048, mode="dot")
+        self.local_attn_1 = TPAVIModule(in_channels=2048, mode="dot")
+        for view in self.view_num:                                       # ours.py:3192-3212: shared with the template, not copied
+            self.init_block_2[view] = nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"])
+            for l in ("layer1", "layer2", "layer3", "layer4"):
+                getattr(self, l + "_2")[view] = bb[l]
+            self.classifier_2[view] = copy.deepcopy(self.network.classifier)
+            self.classifier_2[view][-1] = Conv2d(last.in_channels, 5, kernel_size=last.kernel_size)
+            self.centerness_2[view] = copy.deepcopy(self.network.classifier)
+            self.centerness_2[view][-1] = Conv2d(last.in_channels, 1, kernel_size=last.kernel_size)
+        self.global_attn_2 = TPAVIModule(in_channels=2048, mode="dot")
+        self.local_attn_2 = TPAVIModule(in_channels=2048, mode="dot")
+
+    def _encode(self, sfx: str, view: str, xv: torch.Tensor) -> torch.Tensor:
+        g = lambda name: getattr(self, name + sfx)[view]
+        blk = g("init_block")
+        f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
+        f = blk[3].forward_nhwc(f)
+        for l in ("layer1", "layer2", "layer3", "layer4"):
+            f = g(l).forward_nhwc(f)
+        return f
+
+    def _net(self, x, sfx: str, shared_encoder: bool):
+        views = list(self.view_num)
+        hw = x[views[0]].shape[-2:]
+        ho, wo = int(hw[0]), int(hw[1])
+        g = lambda name: getattr(self, name + sfx)
+
+        def heads_and_gate(v, f):
+            fa, fb, fc, fg = ops.fan_out(f, 4)                          # classifier / centerness / gate / global fusion
+            cls = g("classifier")[v].forward_nhwc(fa)
+            ctr = g("centerness")[v].forward_nhwc(fb)
+            return fg, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+
+        if shared_encoder:               # one set of modules for every view: sequential, the reference's view order
+            f4 = [self._encode(sfx, v, x[v]) for v in views]
+            secs = ops.parallel_sections([lambda v=v, f=f: heads_and_gate(v, f) for v, f in zip(views, f4)])
+        else:
+            secs = ops.parallel_sections([lambda v=v: heads_and_gate(v, self._encode(sfx, v, x[v])) for v in views])
+        g_out, l_out = ops.parallel_sections([
+            lambda: g("global_attn").forward_nvhwc(ops.stack_views([s[0] for s in secs])),
+            lambda: g("local_attn").forward_nvhwc(ops.stack_views([s[1] for s in secs]))])
+        fused = ops.add_views(g_out, l_out)
+        masks = ops.parallel_sections([lambda i=i, v=v: ops.bilinear_up(g("classifier")[v].forward_nhwc(fused[i]), ho, wo)
+                                       for i, v in enumerate(views)])
+        return dict(zip(views, masks)), g_out, l_out
+
+    def forward(self, x: Dict[str, torch.Tensor]):
+        mask, g_out, l_out = self._net(x, "_1", shared_encoder=False)
+        mask_2, _, _ = self._net(x, "_2", shared_encoder=True)
+        f4_g, f4_l = {}, {}
+        for i, v in enumerate(self.view_num):
+            f4_g[v] = g_out[:, i].permute(0, 3, 1, 2)
+            f4_l[v] = l_out[:, i].permute(0, 3, 1, 2)
+            f4_g[v]._glf_stack = (g_out, i)
+            f4_l[v]._glf_stack = (l_out, i)
+        return mask, mask_2, f4_g, f4_l

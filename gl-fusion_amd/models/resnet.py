@@ -31,7 +31,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward_nhwc(self, x):
-        idn = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        # x feeds the shortcut and conv1: its two gradients meet in ONE pass (ops.fan_out) instead of autograd's add
+        x, xs = ops.fan_out(x, 2)
+        idn = xs if self.downsample is None else conv_bn_act(xs, self.downsample[0], self.downsample[1], relu=False)
         out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=idn)      # relu(bn3(.) + identity)

@@ -49,6 +49,23 @@ def _ws(rows: int, c: int, dev) -> torch.Tensor:
     return torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=dev)
 
 
+def zeros(*shape, dtype=torch.float32, device=None) -> torch.Tensor:
+    """Zero-filled device tensor through the library (glf_zero on the current stream), for accumulation targets."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if t.numel():
+        check(lib.glf_zero(_p(t), t.numel() * t.element_size(), _stream()), "zero")
+    return t
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """In-place zero of a DENSE tensor (contiguous storage span) through the library."""
+    if not t.is_contiguous():
+        raise RuntimeError("glfusion_amd: zero_ needs a contiguous tensor")
+    if t.numel():
+        check(lib.glf_zero(_p(t), t.numel() * t.element_size(), _stream()), "zero")
+    return t
+
+
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """NCHW-shaped tensor (any strides) -> contiguous [N,H,W,C]; free for channels_last / C == 1."""
     _chk(x, "input")
@@ -108,6 +125,14 @@ def tap_mask(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, 
 # glf_gemm_params.precision, so nothing process-wide is touched in the library
 _PREC = [0]
 
+TWO_STAGE_SPLITK = os.environ.get("GLF_TWO_STAGE", "1") != "0"
+
+
+def tn_needs_zero(split: int) -> bool:
+    """True when a split-K TN call sums its slices with float atomics (C must then be zero-filled by the caller)."""
+    return split > 1 and not TWO_STAGE_SPLITK
+
+
 # bench.py sets this to a list to time every contraction launch with HIP events on the launch stream
 PROFILER = None
 KERNEL_NAMES = {("nt", False): "gemm_rows_kernel<0,false>", ("nt", True): "gemm_rows_kernel<0,true>",
@@ -138,6 +163,13 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
     p.precision = _PREC[0] + 1
+    ws = None
+    if mode == "tn" and split > 1 and TWO_STAGE_SPLITK:
+        # two-stage reduction: the slices store partial sums, a second kernel adds them in a fixed order -- no atomics, no
+        # zero-filled C, bitwise reproducible gradients
+        nbytes = int(lib.glf_gemm_tn_workspace_bytes(C.byref(p)))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=Cm.device)
+        p.workspace, p.workspace_bytes = _p(ws), nbytes
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -171,7 +203,7 @@ def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     used).  Measured once per tensor and version and remembered on the tensor object; a permutation of the
     elements (weight re-layouts) has the same maximum, so callers pass the owning parameter.  Only call it on
     tensors whose contents are final (raw kernel writes do not bump torch's version counter)."""
-    if t is None or _PREC[0] != 2:
+    if t is None or _PREC[0] < 2:
         return None
     hit = getattr(t, "_glf_amax", None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
@@ -197,12 +229,12 @@ def amax_slot(dev) -> Optional[torch.Tensor]:
     """A zeroed device float for a kernel that reports max|output| as a by-product (None unless f16x3 is
     active).  Slots come from a pre-zeroed pool per stream (one fill kernel per 4096 slots); a used-up pool stays
     alive through the slices that reference it."""
-    if _PREC[0] != 2:
+    if _PREC[0] < 2:
         return None
     key = torch.cuda.current_stream().cuda_stream          # the fill kernel and the users must share a stream
     pool = _amax_pool.get(key)
     if pool is None or pool[1] >= 4096 or pool[0].device != dev:
-        pool = _amax_pool[key] = [torch.zeros(4096, dtype=torch.float32, device=dev), 0]
+        pool = _amax_pool[key] = [zeros(4096, device=dev), 0]
     i = pool[1]
     pool[1] = i + 1
     return pool[0][i:i + 1]
@@ -224,11 +256,11 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     tiles = ((m + 127) // 128) * ((n + 127) // 128) * max(ntaps, 1) * batch
     # workgroups to aim for: 2048 128x128 tiles on the fp32 / bf16x6 kernels (two per CU); the f16x3 kernel has 256-wide
     # tiles, one workgroup per CU, and shares the chip with other streams: 1024 measured best (293.5 vs 299.2 ms / step)
-    target = _TN_TARGET or (1024 if _PREC[0] == 2 else 2048)
+    target = _TN_TARGET or (1024 if _PREC[0] >= 2 else 2048)
     want = max(1, (target + tiles - 1) // tiles)
     cap = max(1, rows // 512)
     hi = 65535 // max(batch, 1)
-    if _TN_ROUND and _PREC[0] == 2:
+    if _TN_ROUND and _PREC[0] >= 2:
         # among the slice counts around the target, the one whose workgroups (256-wide tiles, one per CU) fill whole
         # rounds of the 256 CUs best
         wg = ((m + 255) // 256) * ((n + 127) // 128) * max(ntaps, 1) * batch
@@ -242,6 +274,16 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     return int(max(1, min(want, cap, hi)))
 
 
+_ones_cache = {}
+
+
+def _ones4(dev) -> torch.Tensor:
+    t = _ones_cache.get(dev)
+    if t is None:
+        t = _ones_cache[dev] = torch.ones(4, dtype=torch.float32, device=dev)      # once per process
+    return t
+
+
 def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
     """db[c] = sum_r dy[r][c] (bias gradients)."""
     db = torch.empty(c, dtype=torch.float32, device=dy2d.device)
@@ -250,9 +292,11 @@ def colsum(dy2d: torch.Tensor, rows: int, c: int) -> torch.Tensor:
     else:
         # tiny channel counts (the 5- and 1-channel heads): reduce with the TN contraction against a
         # broadcast 1.0 (row stride 0)
-        one = torch.ones(4, dtype=torch.float32, device=dy2d.device)
-        db.zero_()
-        gemm("tn", dy2d, one, db, M=c, N=1, K=rows, lda=c, ldb=0, ldc=1, split=_tn_split(rows, c, 1, 1))
+        one = _ones4(dy2d.device)
+        sp = _tn_split(rows, c, 1, 1)
+        if tn_needs_zero(sp):
+            zero_(db)
+        gemm("tn", dy2d, one, db, M=c, N=1, K=rows, lda=c, ldb=0, ldc=1, split=sp)
     return db
 
 
@@ -360,12 +404,12 @@ def region_mode(taps: int, kh: int, stride: int, pad: int, dil: int, h: int, w: 
     outputs, 392 workgroups) is faster as per-tap rectangles -- the regions' blocks are fewer and of uneven length
     (4 / 6 / 9 taps) -- and for dilations 1-4 the 5-18 % of padding work saved is less than the extra partial tiles
     and the per-element pixel arithmetic of the epilogue cost."""
-    return (os.environ.get("GLF_REGION", "1") != "0" and _PREC[0] == 2 and taps == 9 and kh == 3 and stride == 1 and pad == dil and h == ho and w == wo
+    return (os.environ.get("GLF_REGION", "1") != "0" and _PREC[0] >= 2 and taps == 9 and kh == 3 and stride == 1 and pad == dil and h == ho and w == wo
             and k % 32 == 0 and frac < RECT_THRESHOLD["region"])
 
 
 def _rect_thr(which: str) -> float:
-    if which == "dgrad" and _PREC[0] == 2:
+    if which == "dgrad" and _PREC[0] >= 2:
         return RECT_THRESHOLD["dgrad_f16x3"]
     return RECT_THRESHOLD[which]
 
@@ -397,7 +441,7 @@ class Conv2dFn(Function):
         rect = (not plain and taps > 1 and stride == 1 and bias is None and bin(mask).count("1") > 1
                 and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("fwd"))
         if rect:
-            y.zero_()
+            zero_(y)
             if colstats is not None:
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
@@ -421,14 +465,14 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             mask = 1 if plain else tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
             if mask == 0:
-                dx = torch.zeros_like(x)
+                dx = zeros(x.shape, device=x.device)
             else:
                 frac = 1.0 if plain or stride != 1 else rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask)
                 if not plain and bin(mask).count("1") > 1 and region_mode(taps, kh, stride, pad, dil, ho, wo, h, w, cout, frac):
                     rect = 2
                 else:
                     rect = int(not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1 and frac < _rect_thr("dgrad"))
-                dx = torch.zeros_like(x) if rect == 1 else torch.empty_like(x)
+                dx = zeros(x.shape, device=x.device) if rect == 1 else torch.empty_like(x)
                 if split_mode() and cout % 32 == 0:
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
                     gemm("nt", dy, tap_major_T(ctx.weight_ref), dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
@@ -447,7 +491,7 @@ class Conv2dFn(Function):
             frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
             split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
             full = mask == (1 << taps) - 1
-            dwt = (torch.empty if (split == 1 and full) else torch.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
+            dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
             gemm("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
                  geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,
@@ -469,7 +513,7 @@ def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1, co
 def conv_stats_fusable(weight, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
     """True when conv2d(..., colstats=) is honoured: f16x3 kernels (Cin % 32 == 0, Cout % 4 == 0) and the conv is not
     one that runs as per-tap rectangles with atomics (ASPP rate 12 / 24 forward)."""
-    if _PREC[0] != 2:
+    if _PREC[0] < 2:
         return False
     cout, cin, kh, kw = weight.shape
     if cin % 32 != 0 or cout % 4 != 0:
@@ -539,7 +583,7 @@ class ConvCatFn(Function):
         split = _tn_split(rows, cout, xs[0].shape[-1], 1)
         dw = None
         if ctx.needs_input_grad[0]:
-            dw = (torch.empty if split == 1 else torch.zeros)(cout, ctot, dtype=torch.float32, device=dy.device)
+            dw = (zeros if tn_needs_zero(split) else torch.empty)(cout, ctot, dtype=torch.float32, device=dy.device)
         db = colsum(dy, rows, cout) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
         grads = []
         off = 0
@@ -564,8 +608,8 @@ class ConvCatFn(Function):
                 grads = [None] * len(xs)
             if dw is not None:
                 split = _tn_split(rows, cout, ctot, 1)
-                if split > 1:
-                    dw.zero_()
+                if tn_needs_zero(split):
+                    zero_(dw)
                 gemm("tn", dy, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
                      amax_a=am_dy, amax_b=amax_of(t0))
             return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
@@ -739,15 +783,11 @@ BN_TAP = None
 def replay_bn_updates(records) -> None:
     """Apply again the running-stat updates recorded by BN_TAP (same batch statistics): what a second forward of the
     same modules over the same input would have done to running_mean / running_var / num_batches_tracked."""
-    with torch.no_grad():
-        for bn, mean, invstd, rows in records:
-            if not bn.track_running_stats or bn.running_mean is None:
-                continue
-            m = float(bn.momentum)
-            var = (invstd.double().pow(-2) - float(bn.eps)).clamp_(min=0.0) * (rows / max(rows - 1, 1))
-            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1.0 - m).add_(var.float(), alpha=m)
-            bn.num_batches_tracked.add_(1)
+    for bn, mean, invstd, rows in records:
+        if not bn.track_running_stats or bn.running_mean is None:
+            continue
+        check(lib.glf_bn_replay_running(_p(mean), _p(invstd), int(rows), mean.numel(), float(bn.eps), float(bn.momentum),
+                                        _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream()), "bn_replay_running")
 
 
 def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None):
@@ -1170,11 +1210,9 @@ class AddViewsFn(Function):
         n, v, h, w, c = ctx.cfg
         inner = h * w * c
         dev = next(d.device for d in dys if d is not None)
-        dg = torch.empty(n, v, h, w, c, dtype=torch.float32, device=dev)
+        dg = (zeros if any(d is None for d in dys) else torch.empty)(n, v, h, w, c, dtype=torch.float32, device=dev)
         for i, d in enumerate(dys):
-            if d is None:
-                dg[:, i].zero_()
-            else:
+            if d is not None:
                 check(lib.glf_copy_frames(_p(_contig(d)), inner, _p(dg[:, i]), v * inner, n, inner, _stream()), "add_views_bwd")
         return dg, dg
 
@@ -1205,11 +1243,9 @@ class SplitViewsFn(Function):
         n, v, h, w, c = ctx.cfg
         inner = h * w * c
         dev = next(d.device for d in dys if d is not None)
-        dg = torch.empty(n, v, h, w, c, dtype=torch.float32, device=dev)
+        dg = (zeros if any(d is None for d in dys) else torch.empty)(n, v, h, w, c, dtype=torch.float32, device=dev)
         for i, d in enumerate(dys):
-            if d is None:
-                dg[:, i].zero_()
-            else:
+            if d is not None:
                 check(lib.glf_copy_frames(_p(_contig(d)), inner, _p(dg[:, i]), v * inner, n, inner, _stream()), "split_views_bwd")
         return dg
 
@@ -1382,7 +1418,7 @@ def dense_seg_cycle(feat, target_region: int = 16, cyc_off: int = 2, chunk_size:
 
 # contraction precision: "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
 # "f16x3" = scaled split-fp16 (3 MFMAs per product).  Host-side setting handed to the library with every call.
-PRECISIONS = ("f32", "bf16x6", "f16x3")
+PRECISIONS = ("f32", "bf16x6", "f16x3", "f16")
 # ----------------------------------------------------------------------------------------
 def set_precision(mode: str) -> None:
     _PREC[0] = PRECISIONS.index(mode)

@@ -60,7 +60,10 @@ int glf_init(void);
  *       (glf_gemm_params.amax_a / amax_b) and split into two fp16 pieces; three
  *       v_mfma_f32_32x32x16_f16 reproduce the fp32 product to 2^-22 relative to the operand maxima
  *       (fp32 accumulate) at 5.3x the fp32-MFMA roof.  Elements more than 2^27 below their operand's
- *       maximum keep an absolute (not relative) error bound, 2^-49 of that maximum.  Same fast-path rule. */
+ *       maximum keep an absolute (not relative) error bound, 2^-49 of that maximum.  Same fast-path rule;
+ *   3 = fp16 "f16": the same kernels keeping only the high fp16 half of each scaled operand -- ONE
+ *       v_mfma_f32_32x32x16_f16 per product, fp32 accumulate, 11-bit operands (relative error ~2^-11 per
+ *       element): the 16-bit-arithmetic configuration (BASELINE.json configs[2]), NOT fp32-equivalent. */
 int glf_set_precision(int mode);
 int glf_get_precision(void);
 /* sizeof(glf_gemm_params) as compiled into the library (binding self-check). */
@@ -118,8 +121,13 @@ typedef struct {
                                 /* the BatchNorm batch statistics of a conv output without a pass over it        */
                                 /* (finish with glf_bn_stats_from_sums).  A call that cannot honour it (exact    */
                                 /* kernels, rect = 1) fails with GLF_ERR_UNSUPPORTED instead of ignoring it.     */
+    float* workspace;           /* glf_gemm_tn with split > 1, may be NULL: caller-owned scratch of at least            */
+    int64_t workspace_bytes;    /* glf_gemm_tn_workspace_bytes(p) bytes.  With it the reduction slices store partial     */
+                                /* sums there and a second kernel adds them in a fixed order: no float atomics, C need   */
+                                /* not be zero-filled, results are bitwise reproducible.  Without it (NULL) the slices   */
+                                /* meet in float atomics and C must be zero-filled (or hold the value to add to).        */
     int32_t precision;          /* contraction precision of THIS call: 0 = the process default (glf_set_precision), */
-                                /* 1 = exact fp32, 2 = split-bf16 x6, 3 = split-fp16 x3 (= 1 + the mode numbers of   */
+                                /* 1 = exact fp32, 2 = split-bf16 x6, 3 = split-fp16 x3, 4 = fp16 x1 (= 1 + the modes of */
                                 /* glf_set_precision).  Two models with different precisions can share a process.   */
 } glf_gemm_params;
 
@@ -143,6 +151,31 @@ int glf_gemm_nn(const float* A, const float* B, const float* bias, float* C,
  * and M = phi^T g of the dot attention.  Output taps are p->tap_stride_b apart in C. */
 int glf_gemm_tn(const float* A, const float* B, float* C,
                 const glf_gemm_params* p, glf_stream_t stream);
+/* bytes of glf_gemm_params.workspace the two-stage reduction of this call needs (0 when p->split <= 1). */
+size_t glf_gemm_tn_workspace_bytes(const glf_gemm_params* p);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused softmax attention of TPAVIModule's `embedded` mode (ours.py:881, 896-897, 902):
+ *   y[n] = softmax(theta[n] phi[n]^T, dim = -1) g[n]      per frame n, theta / phi / g: [L][Ci] rows (row strides ld*).
+ * One kernel per pass; the [L][L] score matrix is never written to memory (online row max / sum over 64-key tiles
+ * staged through LDS, P g accumulated in MFMA accumulators; backward recomputes the tiles from theta, phi and the saved
+ * row log-sum-exp).  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32).  Ci % 32 == 0, Ci <= 1024; frame n of every operand
+ * starts L rows after frame n - 1 (frame stride = L * its row stride).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t frames, L, ci;
+    int64_t ldq, ldk, ldv;      /* row strides of theta, phi, g (elements; column slices of one [rows][3 Ci] buffer: 3 Ci) */
+    int64_t ldy;                /* row stride of y                                                                       */
+    int64_t lddy;               /* backward: row stride of dy                                                            */
+    int64_t ldd;                /* backward: common row stride of dtheta, dphi, dg                                        */
+} glf_attn_params;
+/* y [frames*L][Ci] and lse [frames*L] (row log-sum-exp, needed by the backward pass). */
+int glf_attn_softmax_fwd(const float* theta, const float* phi, const float* g, float* y, float* lse,
+                         const glf_attn_params* p, glf_stream_t stream);
+/* dtheta, dphi, dg from dy (every output element is written exactly once: no zero fill, no atomics).
+ * dsum_ws: caller-owned scratch of frames*L floats. */
+int glf_attn_softmax_bwd(const float* theta, const float* phi, const float* g, const float* y, const float* dy, const float* lse,
+                         float* dtheta, float* dphi, float* dg, float* dsum_ws, const glf_attn_params* p, glf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight layout: torch OIHW [Cout][Cin][kh][kw] <-> tap-major [kh*kw][Cout][Cin].
@@ -181,6 +214,12 @@ int glf_bn_stats(const float* x, int ldx, int rows, int c, float eps, float mome
  * `rows` rows -- the colstats a contraction epilogue accumulated. */
 int glf_bn_stats_from_sums(const double* sums, int rows, int c, float eps, float momentum, float* mean, float* invstd,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked, glf_stream_t s);
+/* Replays the running-statistics update of a train-mode BatchNorm from its saved batch statistics (mean, invstd over
+ * `rows` samples): running_* <- (1 - momentum) running_* + momentum {mean, unbiased var}, num_batches_tracked += 1.
+ * The engine shares the ASPP trunk between the two classifier calls on the same f4 (ours.py:1806, 1840); the second
+ * call's three-fold effect on the buffers is reproduced with this. */
+int glf_bn_replay_running(const float* mean, const float* invstd, int rows, int c, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, glf_stream_t s);
 /* y = [relu]( (x - mean)*invstd*gamma + beta [+ residual] ).  For eval() pass running_mean and
  * 1/sqrt(running_var+eps) (glf_bn_eval_coeffs).  In-place (y == x) allowed.
  * amax_out (may be NULL): device float that must hold 0 (or any lower bound) before the call and
@@ -302,6 +341,8 @@ int glf_axpby(const float* x, const float* y, float* out, float a, float b, int6
 /* y = x * scale * (*scale_dev) (scale_dev: device scalar, may be NULL): a saved gradient times autograd's
  * upstream gradient. */
 int glf_scale(const float* x, float* y, int64_t numel, float scale, const float* scale_dev, glf_stream_t s);
+/* Zero `bytes` bytes at p on the stream (accumulation targets: atomically summed gradients, column statistics, maxima). */
+int glf_zero(void* p, int64_t bytes, glf_stream_t s);
 
 #ifdef __cplusplus
 }

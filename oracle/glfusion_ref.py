@@ -426,6 +426,113 @@ class Local_only(Global_and_Local):
         return mask, mask_bb, atten, f4_l
 
 
+class model19(nn.Module):
+    """ours.py:976-1041: per-view encoders + ONE fusion block named `non_local` (no centre-ness heads, no gate);
+    returns (mask, mask_bb, f4, f4_fusion)."""
+
+    def __init__(self, view_num: Sequence[str], local_attn: bool = False, test_view: Sequence[str] = ("1", "2", "3", "4")) -> None:
+        super().__init__()
+        self.outchannel_list = {"1": 2, "2": 1, "3": 2, "4": 4}
+        self.view_num, self.test_view, self.local_attn = view_num, test_view, local_attn
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)
+        self.init_block = nn.ModuleDict()
+        self.layer1, self.layer2 = nn.ModuleDict(), nn.ModuleDict()
+        self.layer3, self.layer4 = nn.ModuleDict(), nn.ModuleDict()
+        self.classifier = nn.ModuleDict()
+        bb = self.network.backbone
+        for v in self.view_num:                                                    # ours.py:990-1006
+            self.init_block[v] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            self.layer1[v] = copy.deepcopy(bb["layer1"])
+            self.layer2[v] = copy.deepcopy(bb["layer2"])
+            self.layer3[v] = copy.deepcopy(bb["layer3"])
+            self.layer4[v] = copy.deepcopy(bb["layer4"])
+            self.classifier[v] = copy.deepcopy(self.network.classifier)
+            self.classifier[v][-1] = nn.Conv2d(256, 5, kernel_size=1)
+        self.non_local = TPAVIModule(2048, mode="dot")                             # ours.py:1008
+
+    def forward(self, x):
+        hw = x[self.view_num[0]].shape[-2:]
+        f4 = {}
+        for v in self.view_num:                                                    # ours.py:1024-1029
+            f = self.init_block[v](x[v])
+            f = self.layer1[v](f)
+            f = self.layer2[v](f)
+            f = self.layer3[v](f)
+            f4[v] = self.layer4[v](f)
+        out, _ = self.non_local(torch.stack([f4[v] for v in self.view_num], dim=2))               # ours.py:1030-1033
+        f4_fusion = {v: out[:, :, i] for i, v in enumerate(self.view_num)}
+        mask, mask_bb = {}, {}
+        for v in self.view_num:                                                    # ours.py:1036-1041
+            mask[v] = F.interpolate(self.classifier[v](f4_fusion[v].contiguous()), size=hw, mode="bilinear", align_corners=False)
+            mask_bb[v] = F.interpolate(self.classifier[v](f4[v].contiguous()), size=hw, mode="bilinear", align_corners=False)
+        return mask, mask_bb, f4, f4_fusion
+
+
+class Global_and_Local_CPS(nn.Module):
+    """ours.py:3141-3349 (cross pseudo supervision): TWO Global_and_Local networks over the same input.  Network 1 owns
+    deep copies of the template per view; network 2's encoders ARE the template's modules, shared by every view
+    (ours.py:3192-3202: no deepcopy), so `init_block_2.<v>.*` / `layer*_2.<v>.*` alias `network.backbone.*` in the
+    state_dict, their gradients sum over the views and their BatchNorm statistics are updated once per view.  Neither
+    network evaluates the backbone-only mask; returns (mask, mask_2, f4_global_fusion, f4_local_fusion) of network 1."""
+
+    def __init__(self, view_num: Sequence[str], test_view: Sequence[str] = ("1", "2", "3", "4"), center_aware_weight: float = 20) -> None:
+        super().__init__()
+        self.outchannel_list = {"1": 2, "2": 1, "3": 2, "4": 4}
+        self.view_num, self.test_view, self.center_aware_weight = view_num, test_view, center_aware_weight
+        self.network = deeplabv3_resnet50_iekd(pretrained=False, aux_loss=False)
+        for sfx in ("_1", "_2"):                                                   # registration order of ours.py:3150-3165
+            for name in ("init_block", "layer1", "layer2", "layer3", "layer4", "classifier", "centerness"):
+                setattr(self, name + sfx, nn.ModuleDict())
+        bb = self.network.backbone
+        for v in self.view_num:                                                    # ours.py:3167-3187
+            self.init_block_1[v] = copy.deepcopy(nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"]))
+            for l in ("layer1", "layer2", "layer3", "layer4"):
+                getattr(self, l + "_1")[v] = copy.deepcopy(bb[l])
+            self.classifier_1[v] = copy.deepcopy(self.network.classifier)
+            self.classifier_1[v][-1] = nn.Conv2d(256, 5, kernel_size=1)
+            self.centerness_1[v] = copy.deepcopy(self.network.classifier)
+            self.centerness_1[v][-1] = nn.Conv2d(256, 1, kernel_size=1)
+        self.global_attn_1 = TPAVIModule(2048, mode="dot")
+        self.local_attn_1 = TPAVIModule(2048, mode="dot")
+        for v in self.view_num:                                                    # ours.py:3192-3212: shared, not copied
+            self.init_block_2[v] = nn.Sequential(bb["conv1"], bb["bn1"], bb["relu"], bb["maxpool"])
+            for l in ("layer1", "layer2", "layer3", "layer4"):
+                getattr(self, l + "_2")[v] = bb[l]
+            self.classifier_2[v] = copy.deepcopy(self.network.classifier)
+            self.classifier_2[v][-1] = nn.Conv2d(256, 5, kernel_size=1)
+            self.centerness_2[v] = copy.deepcopy(self.network.classifier)
+            self.centerness_2[v][-1] = nn.Conv2d(256, 1, kernel_size=1)
+        self.global_attn_2 = TPAVIModule(2048, mode="dot")
+        self.local_attn_2 = TPAVIModule(2048, mode="dot")
+
+    def _net(self, x, sfx: str):
+        hw = x[self.view_num[0]].shape[-2:]
+        g = lambda name: getattr(self, name + sfx)
+        f4, f4_local = {}, {}
+        for v in self.view_num:
+            f = g("init_block")[v](x[v])
+            for l in ("layer1", "layer2", "layer3", "layer4"):
+                f = g(l)[v](f)
+            f4[v] = f
+        for v in self.view_num:
+            s = torch.sigmoid(g("classifier")[v](f4[v]))
+            m = F.adaptive_max_pool3d(s, (1, s.shape[2], s.shape[3]))
+            c = torch.sigmoid(g("centerness")[v](f4[v]))
+            f4_local[v] = f4[v] * torch.sigmoid(self.center_aware_weight * m * c)
+        g_out, _ = g("global_attn")(torch.stack([f4[v] for v in self.view_num], dim=2))
+        l_out, _ = g("local_attn")(torch.stack([f4_local[v] for v in self.view_num], dim=2))
+        f4_g = {v: g_out[:, :, i] for i, v in enumerate(self.view_num)}
+        f4_l = {v: l_out[:, :, i] for i, v in enumerate(self.view_num)}
+        mask = {v: F.interpolate(g("classifier")[v]((f4_g[v] + f4_l[v]).contiguous()), size=hw, mode="bilinear", align_corners=False)
+                for v in self.view_num}
+        return mask, f4_g, f4_l
+
+    def forward(self, x):
+        mask, f4_g, f4_l = self._net(x, "_1")
+        mask_2, _, _ = self._net(x, "_2")
+        return mask, mask_2, f4_g, f4_l
+
+
 # --------------------------------------------------------------------------------------
 # a8 / a9: the caller's step and metrics (main.py:87,202-243 and main.py:800-815)
 # --------------------------------------------------------------------------------------

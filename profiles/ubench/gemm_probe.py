@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Runs a few of the C2 step's contraction shapes in isolation (random operands) -- the target of rocprofv3 counter
+passes and of A/B timing between library builds (GLF_LIB_PATH).  Usage: gemm_probe.py [precision] [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from glfusion_amd import ops
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ops.set_precision(prec)
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
+
+SHAPES = [("nt", 150528, 3072, 2048), ("nt", 150528, 2048, 1024), ("nt", 50176, 2048, 512), ("nt", 50176, 512, 2048),
+          ("nt", 50176, 256, 1024), ("nt", 50176, 1024, 256), ("tn", 3072, 2048, 150528), ("tn", 2048, 512, 50176)]
+for mode, M, N, K in SHAPES:
+    if mode == "nt":
+        A, B, C = rnd(M, K), rnd(N, K), torch.empty(M, N, device=dev)
+        run = lambda: ops.gemm("nt", A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=ops.amax_of(A), amax_b=ops.amax_of(B))
+    else:
+        A, B = rnd(K, M), rnd(K, N)
+        sp = ops._tn_split(K, M, N, 1)
+        C = torch.zeros(M, N, device=dev)
+        run = lambda: ops.gemm("tn", A, B, C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ops.amax_of(A), amax_b=ops.amax_of(B))
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"{prec} {mode} M={M} N={N} K={K}: {dt * 1e3:.3f} ms  {2.0 * M * N * K / dt / 1e12:.1f} TF fp32-equivalent", flush=True)
+    del A, B, C

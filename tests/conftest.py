@@ -10,8 +10,23 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host on a GPU box whose container owns 16 cores: 8x oversubscription of the oracle's CPU runs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(host_threads())
 
 
 def pytest_collection_modifyitems(config, items):

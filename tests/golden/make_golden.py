@@ -288,7 +288,11 @@ def variants_fixture(ours) -> None:
     """the two single-branch ablations, eval() outputs of the reference's own classes."""
     views, n = ["1", "3"], 2
     imgs = orc.closed_form_images(views, n, 112, 112)
-    for name in ("Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background"):
+    only = [a for a in sys.argv[1:] if a not in ("variants",)]
+    for name in ("Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background",
+                 "model19", "Global_and_Local_CPS"):
+        if only and name not in only:
+            continue
         model = getattr(ours, name)(views)
         orc.closed_form_fill(model, salt=6)
         model.eval()
@@ -365,5 +369,5 @@ if __name__ == "__main__":
     if not args or "variants" in args:
         torch.set_num_threads(max(1, os.cpu_count() or 1))
         variants_fixture(import_reference()[0])
-    if not args or set(args) - {"cycle", "variants", "bottleneck", "kinkfree"}:
+    if not args or set(args) & {"tpavi", "head", "eval", "train"}:
         main()

@@ -138,7 +138,7 @@ def test_config4_two_ranks_at_c2_frame_counts(tmp_path):
     for i in range(world):
         assert r[i]["loss"] == r[i]["loss"] and abs(r[i]["loss"]) < 1e12
         assert abs(r[i]["loss"] - r[i]["loss_local"]) <= 1e-6 * abs(r[i]["loss"])     # same batch, same batch statistics
-    assert r[0]["n_grads"] == r[1]["n_grads"] > 900
+    assert r[0]["n_grads"] == r[1]["n_grads"] > 600
     assert len(r[0]["reduced"]) >= 4
     for n, g0 in r[0]["reduced"].items():
         assert torch.equal(g0, r[1]["reduced"][n]), n

@@ -208,7 +208,6 @@ def _kinkfree_truth(golden_dir):
         return _KINKFREE
     g = np.load(os.path.join(golden_dir, "e2e_train_kinkfree.npz"))
     views, n = [str(v) for v in g["views"]], int(g["n"])
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     ref = orc.Global_and_Local(views)
     orc.kinkfree_fill(ref, salt=21)
     orc.set_dropout(ref, 0.0)
@@ -429,7 +428,8 @@ def _sample(t, k=4099):
     return flat[torch.from_numpy(idx).to(flat.device)]
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background",
+                                  "model19", "Global_and_Local_CPS"])
 def test_variants_eval_vs_golden(golden_dir, name, precision):
     """Global_only / Local_only (ours.py:1999-2249) against outputs of the reference's own classes."""
     import glfusion_amd.models as M
@@ -458,7 +458,7 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
             assert close(_sample(third), torch.from_numpy(g[f"third:{v}"]), 1e-3), v
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge", "Foreground_and_Background"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge", "Foreground_and_Background", "model19", "Global_and_Local_CPS"])
 def test_variants_train_step_vs_oracle(name):
     import glfusion_amd.models as M
     from glfusion_amd import ops
@@ -473,20 +473,30 @@ def test_variants_train_step_vs_oracle(name):
     ref.train()
     imgs = orc.closed_form_images(views, n, 112, 112)
     tgts = orc.closed_form_targets(views, n)
-    want = sum(torch.nn.functional.binary_cross_entropy_with_logits(ref(imgs)[0][v], tgts[v], reduction="sum") for v in views)
+    heads = (0, 1) if name == "Global_and_Local_CPS" else (0,)      # CPS: both networks' masks are supervised
+    out_ref = ref(imgs)
+    want = sum(torch.nn.functional.binary_cross_entropy_with_logits(out_ref[h][v], tgts[v], reduction="sum") for h in heads for v in views)
     want.backward()
-    pred = model({v: t.to(DEV) for v, t in imgs.items()})[0]
-    got = sum(ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
+    out = model({v: t.to(DEV) for v, t in imgs.items()})
+    got = sum(ops.bce_with_logits_sum(out[h][v], tgts[v].to(DEV)) for h in heads for v in views)
     got.backward()
     assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))
     gref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
     have = {k for k, p in model.named_parameters() if p.grad is not None}
     assert have == set(gref)                                  # e.g. Global_only: no gradient reaches the centerness heads
-    attn = "local_attn" if name == "Local_only" else ("merge" if name.endswith("conv_merge") else "global_attn")
+    attn = {"Local_only": "local_attn", "Global_and_Local_conv_merge": "merge", "model19": "non_local",
+            "Global_and_Local_CPS": "global_attn_2"}.get(name, "global_attn")
     top = max(float(w.norm()) for k, w in gref.items() if k.startswith(attn))
     for k, p in model.named_parameters():
         if k.startswith(attn) and k in gref:
             assert float((p.grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm()) + 1e-3 * top, k
+    if name == "Global_and_Local_CPS":
+        # network 2's encoder is the template shared by both views: its gradient is the sum over the views
+        k = "network.backbone.layer4.2.conv3.weight"
+        assert float((dict(model.named_parameters())[k].grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm())
+        sd, sd_ref = model.state_dict(), ref.state_dict()
+        for b in ("network.backbone.bn1.running_mean", "network.backbone.layer4.2.bn3.running_var", "network.backbone.bn1.num_batches_tracked"):
+            assert close(sd[b].float(), sd_ref[b].float(), 1e-4), b          # one update per view of the shared BatchNorm layers
 
 
 def test_temporal_variant_vs_oracle():
@@ -549,7 +559,6 @@ def test_config5_shape_eval_parity_and_linearity():
     from glfusion_amd.models import Global_and_Local
     ops.set_precision("f16x3")
     try:
-        torch.set_num_threads(max(1, os.cpu_count() or 1))
         ref = orc.Global_and_Local(C5_VIEWS)
         orc.closed_form_fill(ref, salt=4)
         ref.eval()
@@ -588,5 +597,53 @@ def test_config5_shape_eval_parity_and_linearity():
         l_t, g_t = grads(0, 4)
         assert l_t == l_t and abs(l_t) < 1e12 and len(g_t) == len(g_all)
         assert all(bool(torch.isfinite(g).all()) for g in g_t.values())
+    finally:
+        ops.set_precision("f32")
+
+
+def test_f16_mode_parity(golden_dir):
+    """Precision "f16" (BASELINE.json configs[2]: 16-bit MFMA arithmetic): every contraction operand rounded to fp16 (11
+    bits, per-tensor power-of-two scale), ONE MFMA per product, fp32 accumulate, fp32 storage.  Not fp32-equivalent; the
+    tolerance stated here is its own: eval logits within 2e-2 (relative to the largest logit) of the reference's,
+    Dice within 5e-3; a train step's loss within 1e-3 and the large gradients within 3e-2 relative L2 of the oracle's."""
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    ops.set_precision("f16")
+    try:
+        g = np.load(os.path.join(golden_dir, "e2e_eval_c2.npz"))
+        views, n = ["1", "3", "4"], 2
+        model = Global_and_Local(views)
+        orc.closed_form_fill(model, salt=1)
+        model = model.to(DEV).eval()
+        imgs = {v: t.to(DEV) for v, t in orc.closed_form_images(views, n).items()}
+        tgts = orc.closed_form_targets(views, n)
+        with torch.no_grad():
+            mask = model(imgs)[0]
+        worst = 0.0
+        for v in views:
+            ref = torch.from_numpy(g[f"mask:{v}"])
+            err = float((mask[v].cpu() - ref).abs().max()) / float(ref.abs().max())
+            worst = max(worst, err)
+            assert err <= 2e-2, (v, err)
+            dice = ops.overlap_metrics_from_counts(ops.overlap_counts(mask[v], tgts[v].to(DEV)))
+            assert abs(dice[1] - float(g[f"dice:{v}"][1])) <= 5e-3, (v, dice[1], float(g[f"dice:{v}"][1]))
+        print("f16 mode: worst relative logit error vs reference", worst)
+        t = _kinkfree_truth(golden_dir)
+        views, n = t["views"], t["n"]
+        model = Global_and_Local(views)
+        orc.kinkfree_fill(model, salt=21)
+        orc.set_dropout(model, 0.0)
+        model = model.to(DEV).train()
+        pred = model({v: t["imgs"][v].to(DEV) for v in views})[0]
+        loss = sum(ops.bce_with_logits_sum(pred[v], t["tgts"][v].to(DEV)) for v in views)
+        loss.backward()
+        assert abs(float(loss) - t["loss"]) <= 1e-3 * abs(t["loss"])
+        worst = (0.0, "")
+        for name, p in model.named_parameters():
+            if name in t["grads"] and float(t["grads"][name].norm()) > 1e-2 * t["scale"][name.split(".")[0]]:
+                rel = float((p.grad.detach().cpu().double() - t["grads"][name]).norm()) / float(t["grads"][name].norm())
+                worst = max(worst, (rel, name))
+        print(f"f16 mode: worst relative L2 gradient error {worst[0]:.2e} ({worst[1]})")
+        assert worst[0] <= 3e-2, worst
     finally:
         ops.set_precision("f32")

@@ -404,7 +404,6 @@ def test_conv2d_real_shapes_fwd_dgrad_wgrad(ops, cfg):
     """forward, dgrad and wgrad at the 2048-channel model shapes against torch's CPU fp32 convolution (oneDNN), each gated
     at 5e-5 in relative L2 -- the bound that protects the reductions (a wgrad that dropped 0.5 % of its rows is at 5e-3)."""
     n, h, w, cin, cout, k, pad, dil = cfg
-    torch.set_num_threads(max(1, __import__("os").cpu_count() or 1))
     x = rnd(n, cin, h, w, seed=20).requires_grad_(True)
     wt = (rnd(cout, cin, k, k, seed=21) / np.sqrt(cin * k * k)).requires_grad_(True)
     y_ref = F.conv2d(x, wt, None, stride=1, padding=pad, dilation=dil)
@@ -463,3 +462,74 @@ def test_f16x3_outlier_and_small_view_operands():
         assert _rel_l2(c[784:1568], ref[784:1568]) <= 1e-5          # 2^-49 amax absolute floor = 2^-19 of this view
     finally:
         _ops.set_precision("f32")
+
+
+# ------------------------------------------------------------------------------------------ fused softmax attention
+def _attn_ref(th, ph, g, dy):
+    th, ph, g = (t.double().requires_grad_(True) for t in (th, ph, g))
+    y = torch.softmax(th @ ph.transpose(1, 2), dim=-1) @ g
+    y.backward(dy.double())
+    return y.detach(), th.grad, ph.grad, g.grad
+
+
+@pytest.mark.parametrize("n,L,ci,scale", [(2, 90, 32, 1.0), (1, 200, 64, 0.5), (3, 64, 128, 0.3), (2, 2352, 1024, 0.05), (1, 15680, 1024, 0.05)])
+def test_fused_softmax_attention_fwd_bwd(n, L, ci, scale):
+    """glf_attn_softmax_{fwd,bwd} (ours.py:881, 896-897, 902 in one kernel per pass) against softmax(theta phi^T) g in
+    fp64 on the host: y and the three gradients within 2e-5 relative L2, on ragged L (90, 200: partial 64-row blocks),
+    the config-2 length 2352 and the config-5 length 15 680, operands read as column slices of one [rows, 3 Ci] buffer."""
+    import ctypes as C
+    from glfusion_amd._lib import AttnParams, check, lib
+    qkv = rnd(n, L, 3 * ci, seed=40) * scale
+    dy = rnd(n, L, ci, seed=41)
+    th, ph, g = qkv[..., :ci], qkv[..., ci:2 * ci], qkv[..., 2 * ci:]
+    y_ref, dth_ref, dph_ref, dg_ref = _attn_ref(th, ph, g, dy)
+    d = qkv.to(DEV)
+    dyd = dy.to(DEV)
+    y = torch.empty(n * L, ci, device=DEV)
+    lse = torch.empty(n * L, device=DEV)
+    dqkv = torch.full((n * L, 3 * ci), float("nan"), device=DEV)          # every element must be written
+    dsum = torch.empty(n * L, device=DEV)
+    ap = AttnParams()
+    ap.frames, ap.L, ap.ci = n, L, ci
+    ap.ldq = ap.ldk = ap.ldv = 3 * ci
+    ap.ldy, ap.lddy, ap.ldd = ci, ci, 3 * ci
+    p = lambda t, off=0: C.c_void_p(t.data_ptr() + 4 * off)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.glf_attn_softmax_fwd(p(d), p(d, ci), p(d, 2 * ci), p(y), p(lse), C.byref(ap), s), "attn fwd")
+    check(lib.glf_attn_softmax_bwd(p(d), p(d, ci), p(d, 2 * ci), p(y), p(dyd), p(lse), p(dqkv), p(dqkv, ci), p(dqkv, 2 * ci), p(dsum),
+                                   C.byref(ap), s), "attn bwd")
+    torch.cuda.synchronize()
+    lse_ref = torch.logsumexp(th.double() @ ph.double().transpose(1, 2), dim=-1).reshape(-1)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) <= 1e-5 * max(1.0, float(lse_ref.abs().max()))
+    assert _rel_l2(y.view(n, L, ci), y_ref) <= 2e-5
+    dq = dqkv.view(n, L, 3 * ci)
+    assert bool(torch.isfinite(dq).all())
+    assert _rel_l2(dq[..., 2 * ci:], dg_ref) <= 2e-5
+    assert _rel_l2(dq[..., ci:2 * ci], dph_ref) <= 2e-5
+    assert _rel_l2(dq[..., :ci], dth_ref) <= 2e-5
+
+
+def test_fused_softmax_matches_materialised_path():
+    """TPAVIModule(mode='embedded') through the fused kernels vs the same module with the scores materialised per frame
+    (three launches + row softmax) at the config-2 length L = 3 x 28 x 28 = 2352: outputs and every gradient agree."""
+    from glfusion_amd import fusion
+    from glfusion_amd.models import TPAVIModule
+    from oracle import glfusion_ref as orc
+    res = {}
+    for fused in (True, False):
+        fusion.FUSED_SOFTMAX = fused
+        try:
+            m = TPAVIModule(256, mode="embedded")
+            orc.closed_form_fill(m, salt=3)
+            m = m.to(DEV).train()
+            x = (orc.closed_form_tensor((2, 256, 3, 28, 28), 101, -1.0, 1.0) * 0.5).to(DEV).requires_grad_(True)
+            z, _ = m(x)
+            (z * orc.closed_form_tensor(tuple(z.shape), 102, -1.0, 1.0).to(DEV)).sum().backward()
+            res[fused] = (z.detach(), x.grad, {k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            fusion.FUSED_SOFTMAX = True
+    assert _rel_l2(res[True][0], res[False][0]) <= 1e-5
+    assert _rel_l2(res[True][1], res[False][1]) <= 1e-4
+    for k, gk in res[False][2].items():
+        if k != "W_z.0.bias":                                  # exactly-zero true gradient (feeds a train-mode BN)
+            assert _rel_l2(res[True][2][k], gk) <= 1e-4, k

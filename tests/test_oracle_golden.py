@@ -219,7 +219,6 @@ def test_kinkfree_train_step_oracle_vs_reference(golden_dir):
     gradient samples, BatchNorm running statistics."""
     g = np.load(os.path.join(golden_dir, "e2e_train_kinkfree.npz"))
     views, n = [str(v) for v in g["views"]], int(g["n"])
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     model = orc.Global_and_Local(views)
     orc.kinkfree_fill(model, salt=21)
     orc.set_dropout(model, 0.0)
