@@ -108,17 +108,45 @@ class Trainer:
             self.save(epoch)
 
     @torch.no_grad()
-    def eval(self, net_path: str = None, is_fuse: bool = True, raw_data: bool = True):
-        """main.py:417-543 shape contract: clip [1,1,H,W,T] -> [T,1,H,W] frames, sigmoid > 0.5, overlap metrics."""
+    def eval(self, net_path: str = None, is_fuse: bool = True, raw_data: bool = True, patients=None):
+        """main.py:417-543.  Per patient and view a raw clip volume goes through the data path (data.prepare_frames: the
+        loader's resize / centre crop / part masks / 255 and the `[1,1,H,W,T] -> [T,1,H,W]` reshape of main.py:495-499),
+        the model predicts all frames of the clip (the fused mask, or the backbone mask when is_fuse is False, main.py:
+        504-506), BCE-sum losses accumulate per view (main.py:510-512) and the overlap counters accumulate over patients
+        -- tp / fp / fn / tn are additive, so the reference's concatenation of every prediction (main.py:514-516) is not
+        needed.  Returns {view: (pixel_acc, dice, precision, specificity, recall)} (main.py:519); the per-part Dice of
+        main.py:537-543 and the losses are left in `self.eval_report`."""
+        from .data import SyntheticPatients, part_overlap_counts
+        from . import data as _data
         if net_path and os.path.exists(net_path):
             self.model.load_state_dict(torch.load(net_path, map_location=self.device)["network"], strict=True)
         self.model.eval()
-        out = {}
-        imgs, masks = self.loader.batch()
-        mask, _, _, _ = self.model(imgs)
+        if patients is None:
+            patients = SyntheticPatients(self.view_num, int(self.config["train"].get("eval_patients", 2)),
+                                         int(self.config["train"].get("clip_length", 40)), device=self.device, seed=77)
+        counts = {v: torch.zeros(5, 4, dtype=torch.int64, device=self.device) for v in self.test_view}
+        loss4view = {v: 0.0 for v in self.test_view}
+        for sample in patients:
+            imgs, masks = {}, {}
+            for v in self.view_num:
+                imgs[v], masks[v] = _data.prepare_frames(sample[v][0], sample[v][1], v, train=False)
+            out = self.model(imgs)
+            pred = out[0] if is_fuse else out[1]
+            for v in self.test_view:
+                counts[v] += part_overlap_counts(pred[v], masks[v])
+                loss4view[v] += float(ops.bce_with_logits_sum(pred[v], masks[v]))
+        result, part_dice = {}, {}
         for v in self.test_view:
-            out[v] = self._calculate_overlap_metrics(masks[v], mask[v])
-        return out
+            per_part = all_reduce_counts(counts[v])
+            result[v] = ops.overlap_metrics_from_counts(per_part.sum(dim=0))
+            part_dice[v] = [ops.overlap_metrics_from_counts(per_part[c])[1] for c in range(5)]
+        self.eval_report = {"loss": loss4view, "part_dice": part_dice}
+        if self.print_val:
+            for v in self.test_view:
+                print(f"validation view {v}: loss {loss4view[v]:.4f} pixel-acc {result[v][0]:.4f} dice {result[v][1]:.4f} "
+                      f"precision {result[v][2]:.4f} specificity {result[v][3]:.4f} recall {result[v][4]:.4f}; part dice "
+                      + " ".join(f"{d:.4f}" for d in part_dice[v]))
+        return result
 
     def _calculate_overlap_metrics(self, gt, logits, eps: float = 1e-5):
         """main.py:800-815 on pred = (sigmoid(logits) > 0.5); counters reduced over ranks."""

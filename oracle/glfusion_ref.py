@@ -724,6 +724,48 @@ def dense_seg_cycle(feat: torch.Tensor, target_region: int = 16, cyc_off: int = 
     return total / n
 
 
+# ------------------------------------------------------------------------------------------------
+# data path + evaluation harness: datasets/loader.py:298-330, 358-414, 460-498; main.py:484-543
+# ------------------------------------------------------------------------------------------------
+def mask_to_allclass(masks: torch.Tensor, view: str) -> torch.Tensor:
+    """loader.py:358-414: the per-view part masks [k, ...] re-ordered into 5 class channels."""
+    out = torch.zeros(5, *masks.shape[1:])
+    if view in ("1", "3"):
+        out[1] = masks[1]; out[3] = masks[0]
+    elif view == "2":
+        out[4] = masks[0]
+    elif view == "4":
+        out[0] = masks[2]; out[1] = masks[3]; out[2] = masks[1]; out[3] = masks[0]
+    else:
+        raise KeyError(view)
+    return out
+
+
+def prepare_clip(images: torch.Tensor, labels: torch.Tensor, view: str, crop_offset=None, labelled: bool = True):
+    """The sample path of Seg_PAHDataset.__getitem__ for one view in torch CPU ops: AddChannel, Resized((144, 144, T),
+    mode='nearest') == F.interpolate(mode='nearest') on the two spatial axes (the frame axis keeps its size), crop 112 x 112
+    at `crop_offset` (centre when None: CenterSpatialCropd, loader.py:489), part masks (loader.py:298-316) ->
+    mask_to_allclass, images / 255 (loader.py:327); then the frame reshape of main.py:495-499: [1,H,W,T] -> [T,1,H,W].
+    images / labels: [H0, W0, T].  Returns (frames [T,1,112,112], masks [T,5,112,112])."""
+    t = images.shape[-1]
+    img = F.interpolate(images.permute(2, 0, 1).unsqueeze(1).float(), size=(144, 144), mode="nearest")     # [T,1,144,144]
+    lab = F.interpolate(labels.permute(2, 0, 1).unsqueeze(1).float(), size=(144, 144), mode="nearest")
+    oy, ox = (16, 16) if crop_offset is None else crop_offset
+    img = img[:, :, oy:oy + 112, ox:ox + 112]
+    lab = lab[:, 0, oy:oy + 112, ox:ox + 112]                                                               # [T,112,112]
+    k = {"1": 2, "2": 1, "3": 2, "4": 4}[view]
+    parts = torch.stack([torch.where(lab == c, 1, 0) for c in range(1, k + 1)], dim=0).float()             # loader.py:298-316
+    masks = mask_to_allclass(parts, view).permute(1, 0, 2, 3).contiguous()                                  # [T,5,112,112]
+    return (img / 255.0 if labelled else img).contiguous(), masks
+
+
+def eval_metrics(all_pred: torch.Tensor, all_mask: torch.Tensor):
+    """main.py:519 and 537-543: overlap metrics of the whole view, then Dice per part channel."""
+    whole = overlap_metrics(all_mask, binarize(all_pred))
+    parts = [overlap_metrics(all_mask[:, c], binarize(all_pred[:, c]))[1] for c in range(all_pred.shape[1])]
+    return [float(x) for x in whole], [float(x) for x in parts]
+
+
 def set_dropout(module: nn.Module, p: float) -> None:
     for m in module.modules():
         if isinstance(m, nn.Dropout):
