@@ -22,7 +22,7 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
 // img / lab: [H0][W0][T] (T fastest, the NIfTI volume order nibabel hands over); out_img [T][1][oh][ow]; out_mask [T][5][oh][ow]
 __global__ __launch_bounds__(256) void prepare_frames_kernel(const float* __restrict__ img, const float* __restrict__ lab,
                                                              float* __restrict__ out_img, float* __restrict__ out_mask, int H0, int W0, int T,
-                                                             int rs, int oh, int ow, int oy, int ox, int4 chan_lo, int chan_4, float img_scale) {
+                                                             int rs, int oh, int ow, int oy, int ox, int4 chan_lo, int chan_4, float img_div) {
     const long long total = (long long)T * oh * ow;
     const float sy = (float)H0 / (float)rs, sx = (float)W0 / (float)rs;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void prepare_frames_kernel(const float* __rest
         const int t = (int)(i / ((long long)ow * oh));
         const int ys = nearest_src(y + oy, sy, H0), xs = nearest_src(x + ox, sx, W0);
         const long long src = ((long long)ys * W0 + xs) * T + t;
-        if (out_img) out_img[i] = img[src] * img_scale;
+        if (out_img) out_img[i] = img[src] / img_div;              // a true division: bit-identical to `images / 255.0` (loader.py:327)
         if (out_mask) {
             const int cls = (int)lab[src];                      // 0 = background, 1..4 = parts of this view
             const int ch = cls == 1 ? chan_lo.x : cls == 2 ? chan_lo.y : cls == 3 ? chan_lo.z : cls == 4 ? chan_lo.w : -1;
@@ -69,13 +69,14 @@ __global__ __launch_bounds__(256) void overlap_nchw_kernel(const float* __restri
 }  // namespace
 
 extern "C" int glf_prepare_frames(const float* img, const float* lab, float* out_img, float* out_mask, int H0, int W0, int T,
-                                  int resize, int out_h, int out_w, int off_y, int off_x, const int* class_to_channel, float img_scale,
+                                  int resize, int out_h, int out_w, int off_y, int off_x, const int* class_to_channel, float img_div,
                                   glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE((img && out_img) || (lab && out_mask), GLF_ERR_NULL, "prepare_frames: nothing to do (image and label both missing)");
     GLF_REQUIRE((img != nullptr) == (out_img != nullptr) && (lab != nullptr) == (out_mask != nullptr), GLF_ERR_NULL,
                 "prepare_frames: an input needs its output and vice versa");
     GLF_REQUIRE(H0 > 0 && W0 > 0 && T > 0 && resize > 0 && out_h > 0 && out_w > 0, GLF_ERR_BAD_SHAPE, "prepare_frames: sizes must be > 0");
+    GLF_REQUIRE(img_div != 0.f, GLF_ERR_BAD_SHAPE, "prepare_frames: img_div must not be 0");
     GLF_REQUIRE(off_y >= 0 && off_x >= 0 && off_y + out_h <= resize && off_x + out_w <= resize, GLF_ERR_BAD_SHAPE,
                 "prepare_frames: crop window [%d+%d, %d+%d] leaves the %d x %d resized image", off_y, out_h, off_x, out_w, resize, resize);
     int4 lo = make_int4(-1, -1, -1, -1);
@@ -89,7 +90,7 @@ extern "C" int glf_prepare_frames(const float* img, const float* lab, float* out
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(prepare_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, glf::S(s), img, lab, out_img, out_mask, H0, W0, T, resize,
-                       out_h, out_w, off_y, off_x, lo, 0, img_scale);
+                       out_h, out_w, off_y, off_x, lo, 0, img_div);
     return glf::check_launch("prepare_frames");
 }
 

@@ -66,7 +66,7 @@ def prepare_frames(images: Optional[torch.Tensor], labels: Optional[torch.Tensor
         masks = torch.empty(t, 5, CROP, CROP, dtype=torch.float32, device=dev)
     table = (C.c_int * 4)(*CLASS_TO_CHANNEL[view])
     check(lib.glf_prepare_frames(_p(images), _p(labels), _p(frames), _p(masks), h0, w0, t, RESIZE, CROP, CROP, oy, ox, table,
-                                 1.0 / 255.0 if labelled else 1.0, _stream()), "prepare_frames")
+                                 255.0 if labelled else 1.0, _stream()), "prepare_frames")
     return frames, masks
 
 

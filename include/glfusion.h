@@ -344,7 +344,7 @@ int glf_scale(const float* x, float* y, int64_t numel, float scale, const float*
 /* ---------------------------------------------------------------------------------------
  * Data path and evaluation harness.
  * glf_prepare_frames: one raw volume [H0][W0][T] (T fastest; img = grey levels, lab = class ids 0..4, either may be
- * NULL with its output) -> frames out_img [T][1][out_h][out_w] = img / 255 (img_scale = 1/255; 1 for unlabelled clips,
+ * NULL with its output) -> frames out_img [T][1][out_h][out_w] = img / img_div (255 for labelled, 1 for unlabelled clips,
  * loader.py:325-327) and part masks out_mask [T][5][out_h][out_w]: nearest-neighbour resize to resize x resize
  * (Resized(mode='nearest'), loader.py:478, 488), crop window at (off_y, off_x) (RandSpatialCropd / CenterSpatialCropd,
  * loader.py:480, 489: centre = (resize - out) / 2), class id k = 1..4 -> channel class_to_channel[k-1] (HOST array of 4
@@ -353,7 +353,7 @@ int glf_scale(const float* x, float* y, int64_t numel, float scale, const float*
  * [n][c][hw] tensors (the per-part Dice of main.py:537-543); counts is zeroed by the call.
  * ------------------------------------------------------------------------------------- */
 int glf_prepare_frames(const float* img, const float* lab, float* out_img, float* out_mask, int H0, int W0, int T,
-                       int resize, int out_h, int out_w, int off_y, int off_x, const int* class_to_channel, float img_scale,
+                       int resize, int out_h, int out_w, int off_y, int off_x, const int* class_to_channel, float img_div,
                        glf_stream_t s);
 int glf_overlap_counts_nchw(const float* logits, const float* target, int64_t* counts, int n, int c, int64_t hw, glf_stream_t s);
 /* Zero `bytes` bytes at p on the stream (accumulation targets: atomically summed gradients, column statistics, maxima). */

@@ -249,6 +249,7 @@ def kinkfree_fixture(ours) -> None:
     tgts = orc.closed_form_targets(views, n)
     bce = torch.nn.BCEWithLogitsLoss(reduction="sum")
     d = {"views": np.array(views), "n": np.array(n)}
+    g32 = {}
     for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
         model = ours.Global_and_Local(view_num=views)
         orc.kinkfree_fill(model, salt=21)
@@ -258,16 +259,23 @@ def kinkfree_fixture(ours) -> None:
         loss = sum(bce(pred[v], tgts[v].to(dt)) for v in views)
         loss.backward()
         d["loss" + sfx] = np.array(float(loss.detach()))
-        names, norms = [], []
+        names, norms, noise = [], [], []
         for name, p_ in model.named_parameters():
             names.append(name)
             if p_.grad is None:
                 norms.append(-1.0)
+                noise.append(-1.0)
                 continue
             g = p_.grad.detach().double().reshape(-1)
             norms.append(float(g.norm()))
-            if sfx == "64":
+            if sfx == "32":
+                g32[name] = p_.grad.detach().reshape(-1).clone()
+            else:
                 d["g64:" + name] = t2n(g[torch.from_numpy(sample_idx(g.numel(), 65))].float())
+                # the reference's OWN fp32-vs-fp64 deviation on this tensor (relative L2): the yardstick for any fp32 engine
+                noise.append(float((g32.pop(name).double() - g).norm()) / max(float(g.norm()), 1e-300))
+        if sfx == "64":
+            d["grad_noise32"] = np.array(noise)
         d["grad_names"] = np.array(names)
         d["grad_norms" + sfx] = np.array(norms)
         for v in views:

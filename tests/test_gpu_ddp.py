@@ -115,8 +115,12 @@ def _c4_worker(rank, world, port, tmp):
         loss.backward()
         return float(loss.detach())
 
-    loss_local = step()                                          # 1: this rank's own gradients (no exchange)
-    local = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None and keep(n)}
+    loss_local = step()                                          # 1: a pass without exchange (loss reproducibility)
+    # this rank's OWN gradients of the reducing pass, captured by hooks that run before the reducer's (registration order)
+    local = {}
+    for n, p in model.named_parameters():
+        if keep(n):
+            p.register_post_accumulate_grad_hook(lambda q, n=n: local.__setitem__(n, q.grad.detach().cpu().clone()))
     red = GradAllReducer(model)                                  # default 48 MB buckets, as bench.py / engine.Trainer
     red.broadcast_parameters(0)
     loss = step()                                                # 2: same batch, hooks armed
@@ -137,13 +141,13 @@ def test_config4_two_ranks_at_c2_frame_counts(tmp_path):
     r = [torch.load(tmp_path / f"c4_{i}.pt") for i in range(world)]
     for i in range(world):
         assert r[i]["loss"] == r[i]["loss"] and abs(r[i]["loss"]) < 1e12
-        assert abs(r[i]["loss"] - r[i]["loss_local"]) <= 1e-6 * abs(r[i]["loss"])     # same batch, same batch statistics
+        assert abs(r[i]["loss"] - r[i]["loss_local"]) <= 1e-5 * abs(r[i]["loss"])     # same batch, same batch statistics
     assert r[0]["n_grads"] == r[1]["n_grads"] > 600
     assert len(r[0]["reduced"]) >= 4
     for n, g0 in r[0]["reduced"].items():
         assert torch.equal(g0, r[1]["reduced"][n]), n
         want = r[0]["local"][n].double() + r[1]["local"][n].double()
-        assert float((g0.double() - want).norm()) <= 1e-5 * float(want.norm()), n     # wgrad split-K atomics reorder sums between passes
+        assert float((g0.double() - want).norm()) <= 1e-6 * float(want.norm()), n     # a two-term fp32 sum: order-free
     print("config-4 rank peak memory (GB):", [round(x["peak_gb"], 1) for x in r])
 
 

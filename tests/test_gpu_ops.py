@@ -530,6 +530,7 @@ def test_fused_softmax_matches_materialised_path():
             fusion.FUSED_SOFTMAX = True
     assert _rel_l2(res[True][0], res[False][0]) <= 1e-5
     assert _rel_l2(res[True][1], res[False][1]) <= 1e-4
+    top = max(float(gk.norm()) for gk in res[False][2].values())
     for k, gk in res[False][2].items():
-        if k != "W_z.0.bias":                                  # exactly-zero true gradient (feeds a train-mode BN)
-            assert _rel_l2(res[True][2][k], gk) <= 1e-4, k
+        if float(gk.norm()) > 1e-5 * top:                      # W_z.0.bias, g.bias: exactly-zero true gradients (a constant
+            assert _rel_l2(res[True][2][k], gk) <= 1e-4, k     # shift in front of a train-mode BatchNorm): rounding noise only

@@ -238,6 +238,8 @@ def test_kinkfree_train_step_oracle_vs_reference(golden_dir):
         assert close(flat[torch.from_numpy(idx)], g[f"mask64:{v}"], 1e-4), v
     names = [str(k) for k in g["grad_names"]]
     norms64 = dict(zip(names, n64.tolist()))
+    noise32 = dict(zip(names, g["grad_noise32"].tolist()))
+    assert float(np.median(g["grad_noise32"][live])) < 1e-4        # the reference's fp32-vs-fp64 relative L2, median over tensors
     scale = {}
     for k, v in norms64.items():
         scale[k.split(".")[0]] = max(scale.get(k.split(".")[0], 0.0), v)
@@ -246,7 +248,7 @@ def test_kinkfree_train_step_oracle_vs_reference(golden_dir):
             assert p.grad is None, name
             continue
         gn = float(p.grad.double().norm())
-        tol = 1e-3 * norms64[name] + 1e-5 * scale[name.split(".")[0]]
+        tol = max(1e-3, 5.0 * noise32[name]) * norms64[name] + 1e-5 * scale[name.split(".")[0]]
         assert abs(gn - norms64[name]) <= tol, (name, gn, norms64[name])
         flat = p.grad.reshape(-1)
         idx = np.unique(np.linspace(0, flat.numel() - 1, num=min(65, flat.numel())).astype(np.int64))
