@@ -23,6 +23,7 @@ struct GemmArgs {
     float* amax_c;                              // f16x3 only: receives max(*amax_c, max|C written|) (null = not wanted)
     double* colstats;                           // f16x3 NT only: [2][N] += column sums of C and of C^2 (null = not wanted)
     float* partial;                             // TN only: partial-sum slabs [batch*split][kept taps][M][N] (null = atomics into C)
+    int flags;                                  // f16x3 rows kernel: bit 0 = waves 4-7 run at s_setprio 1 (the younger half of an 8-wave workgroup)
 };
 constexpr int ZERO_PAGE_FLOATS = 1 << 18;
 
@@ -179,7 +180,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
-    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr; a.flags = 0;
     return a;
 }
 

@@ -19,6 +19,18 @@
 // gemm_bf16s.hip, with two planes per operand instead of three (96 KB of LDS).  Only the aligned fast path is
 // built; everything else stays on the exact-fp32 kernels.
 #include "gemm_common.h"
+#include <cstdlib>
+
+// default MFMA shape of the NT kernel: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 (GLF_MFMA16 overrides)
+#ifndef GLF_MFMA16_DEFAULT
+#define GLF_MFMA16_DEFAULT false
+#endif
+#ifndef GLF_GROUP_M_DEFAULT
+#define GLF_GROUP_M_DEFAULT 0
+#endif
+#ifndef GLF_SETPRIO_DEFAULT
+#define GLF_SETPRIO_DEFAULT 0
+#endif
 
 namespace {
 
@@ -27,6 +39,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SplitH { f16x4 h, l; };
 
@@ -83,7 +96,12 @@ constexpr int PL_A8 = BM8 * 64, PL_B8 = BN * 64;
 constexpr int BUF8 = 2 * PL_A8 + 2 * PL_B8;
 constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 
-template <bool GATHER, int NP>
+// M16: the products run on v_mfma_f32_16x16x32_f16 (16 x 16 output tiles, the whole 32-deep K-tile per instruction)
+// instead of v_mfma_f32_32x32x16_f16: the same MFMA cycles per FLOP, the same LDS fragment traffic, but under load the
+// chip holds a higher clock on the smaller shape (MI355X_MICROARCH.md, DVFS item 7).  LDS rows keep their 64-byte
+// layout; only the 16-byte chunk swizzle differs (chunk g(c) ^ (row >> 2 & 3), g = 0,3,1,2: conflict-free ds_read_b128 for
+// the lane -> (row = lane & 15, chunk = lane >> 4) fragment map).
+template <bool GATHER, int NP, bool M16>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -107,8 +125,26 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % p_tiles_n;
-    int tm = bid / p_tiles_n;
+    // tile order inside an XCD's contiguous range: groups of `gm` row tiles x all column tiles, walked down the rows first, so
+    // that the ~32 workgroups an XCD runs at a time form a gm x (32 / gm) block of tiles: each A row tile is shared by 32 / gm
+    // of them and each B column tile by gm of them through that XCD's L2 (gm = 0: the plain row-major order, every B tile
+    // fetched from the Infinity Cache once per row tile)
+    int tn, tm;
+    {
+        const int gm = (args.flags >> 8) & 0xff;
+        if (gm > 1) {
+            const int tiles_m_all = gridDim.x / p_tiles_n;
+            const int per_group = gm * p_tiles_n;
+            const int grp = bid / per_group, in_grp = bid - grp * per_group;
+            const int first_m = grp * gm;
+            const int gsz = min(tiles_m_all - first_m, gm);
+            tn = in_grp / gsz;
+            tm = first_m + (in_grp - tn * gsz);
+        } else {
+            tn = bid % p_tiles_n;
+            tm = bid / p_tiles_n;
+        }
+    }
     int pMe = pM;
     int r_y0 = 0, r_x0 = 0, r_h = g_hd, r_w = g_wd;
     unsigned mask = p_tap_mask;
@@ -182,6 +218,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 
     const int nkc = pK / BK;
     const int ntiles = __popc(mask) * nkc;
+    if ((args.flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half (no per-phase flips)
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};      // main products
     f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};      // mixed products (x 2^11)
     float4 ra[4], rb[2];
@@ -220,7 +257,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         }
     };
     // swizzled staging offset of this thread inside a 64-byte row: 16-byte chunk (ac>>1) ^ ((row>>2)&3), half ac&1
-    const int st_off = ar * 64 + ((((ac >> 1) ^ ((ar >> 2) & 3)) << 4) | ((ac & 1) << 3));
+    const int st_chunk = M16 ? (int)((0x2130u >> (4 * (ac >> 1))) & 3u) : (ac >> 1);      // g = 0,3,1,2 for the 16x16x32 fragment map
+    const int st_off = ar * 64 + (((st_chunk ^ ((ar >> 2) & 3)) << 4) | ((ac & 1) << 3));
 #define GLF_H8_CONV_A(J, buf_)                                                                               \
     {                                                                                                        \
         const SplitH s = split4h(ra[J], sc_a);                                                               \
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); break; \
     }
 
-    if (ntiles > 0) {
+    if (!M16 && ntiles > 0) {
         const int sw = (lane >> 2) & 3, hh = lane >> 5;
         const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
         const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
@@ -316,65 +354,169 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         GLF_H8_BODY(false, false, false)
     }
 
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    float cmax = 0.f;
-    const bool p_colstats = args.colstats != nullptr;
-    // cs / cq: this lane's column sum and sum of squares over the rows it stores (colstats)
-    auto emit = [&](const f32x16& acc, int ti, int tj, double& cs, double& cq) {
-        const int col = tn * BN + wn + 32 * tj + col_l;
-        if (col >= pN) return;
-        const float bv = p_bias ? p_bias[col] : 0.f;
+
+    // ---- 16x16x32 variant: accumulators t[i][j] (main) / u[i][j] (mixed), i = 16-row slab, j = 16-column slab of the
+    //      wave's 64 x 64 tile ----
+    f32x4 t00 = {0}, t01 = {0}, t02 = {0}, t03 = {0}, t10 = {0}, t11 = {0}, t12 = {0}, t13 = {0};
+    f32x4 t20 = {0}, t21 = {0}, t22 = {0}, t23 = {0}, t30 = {0}, t31 = {0}, t32 = {0}, t33 = {0};
+    f32x4 u00 = {0}, u01 = {0}, u02 = {0}, u03 = {0}, u10 = {0}, u11 = {0}, u12 = {0}, u13 = {0};
+    f32x4 u20 = {0}, u21 = {0}, u22 = {0}, u23 = {0}, u30 = {0}, u31 = {0}, u32 = {0}, u33 = {0};
+    if (M16 && ntiles > 0) {
+        const int lr = lane & 15;
+        const int fo = lr * 64 + (((int)((0x2130u >> (4 * (lane >> 4))) & 3u) ^ ((lr >> 2) & 3)) << 4);
+        advance();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tm * BM8 + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
-            if (row < pMe) {
-                if (p_rect) {
-                    const int hw = r_h * r_w;
-                    const int n = row / hw, rem = row - n * hw;
-                    const int yy = rem / r_w;
-                    const long long orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
-                    if (p_rect == 2) {                    // regions partition the output: plain store
-                        float* dst = C + orow * p_ldc + col;
-                        float v = p_alpha * acc[r] + bv;
-                        if (p_accumulate) v += *dst;
-                        *dst = v;
-                        cmax = fmaxf(cmax, fabsf(v));
-                        if (p_colstats) { const double vd = (double)v; cs += vd; cq = fma(vd, vd, cq); }
-                    } else {
-                        atomicAdd(C + orow * p_ldc + col, p_alpha * acc[r]);
-                    }
-                } else {
-                    float* dst = C + (long long)row * p_ldc + col;
-                    float v = p_alpha * acc[r] + bv;
-                    if (p_accumulate) v += *dst;
-                    *dst = v;
-                    cmax = fmaxf(cmax, fabsf(v));
-                    if (p_colstats) { const double vd = (double)v; cs += vd; cq = fma(vd, vd, cq); }
-                }
+        for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, false, true) }
+        {
+            const bool more = ntiles > 1;
+            if (more) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, true, more) }
+            if (more) {
+                const bool more2 = ntiles > 2;
+                if (more2) advance();
+#pragma unroll
+                for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 1, true, more2) }
             }
         }
+        __syncthreads();
+#define GLF_MFMA_16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+        // one 16-row slab of A against one 16-column slab of B: main product into t, the two mixed ones into u
+#define GLF_M16_TILE(t, u, ah, al, bh, bl)                          \
+        t = GLF_MFMA_16(ah, bh, t);                                 \
+        if (NP == 3) { u = GLF_MFMA_16(al, bh, u); u = GLF_MFMA_16(ah, bl, u); }
+#define GLF_M16_A(buf_, s_, dh, dl)                                                                             \
+        {                                                                                                       \
+            const unsigned char* p_ = smem_s + (buf_) * BUF8 + (wm + 16 * (s_)) * 64 + fo;                      \
+            dh = *reinterpret_cast<const f16x8*>(p_);                                                           \
+            if (NP == 3) dl = *reinterpret_cast<const f16x8*>(p_ + PL_A8); else dl = dh;                        \
+        }
+#define GLF_M16_B(buf_, s_, dh, dl)                                                                             \
+        {                                                                                                       \
+            const unsigned char* p_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + (wn + 16 * (s_)) * 64 + fo;          \
+            dh = *reinterpret_cast<const f16x8*>(p_);                                                           \
+            if (NP == 3) dl = *reinterpret_cast<const f16x8*>(p_ + PL_B8); else dl = dh;                        \
+        }
+        f16x8 a0h, a0l, a1h, a1l, a2h, a2l, a3h, a3l, b0h, b0l, b1h, b1l, b2h, b2l, b3h, b3l;
+        GLF_M16_B(0, 0, b0h, b0l) GLF_M16_B(0, 1, b1h, b1l) GLF_M16_B(0, 2, b2h, b2l) GLF_M16_B(0, 3, b3h, b3l)
+        GLF_M16_A(0, 0, a0h, a0l) GLF_M16_A(0, 1, a1h, a1l)
+        int cur = 0, nxt = 1, wr = 2;
+        // Per iteration: slabs 0, 1 of A (loaded one iteration ahead) against all of B while slabs 2, 3 arrive; then slabs 2, 3
+        // column by column, each B slab being replaced by the next tile's as soon as its last product is issued, and slabs
+        // 0, 1 of the next tile are fetched at the half-way point: 64 fragment registers in all, nothing exposed behind the barrier.
+#define GLF_M16_BODY(CONV_, LOAD_, NEXT_)                                                                     \
+        {                                                                                                     \
+            if (LOAD_) advance();                                                                             \
+            GLF_M16_A(cur, 2, a2h, a2l) GLF_M16_A(cur, 3, a3h, a3l)                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_H8_PIECE(0, wr, CONV_, LOAD_)                                                                 \
+            GLF_M16_TILE(t00, u00, a0h, a0l, b0h, b0l) GLF_M16_TILE(t01, u01, a0h, a0l, b1h, b1l)             \
+            GLF_M16_TILE(t02, u02, a0h, a0l, b2h, b2l) GLF_M16_TILE(t03, u03, a0h, a0l, b3h, b3l)             \
+            GLF_H8_PIECE(1, wr, CONV_, LOAD_)                                                                 \
+            GLF_M16_TILE(t10, u10, a1h, a1l, b0h, b0l) GLF_M16_TILE(t11, u11, a1h, a1l, b1h, b1l)             \
+            GLF_M16_TILE(t12, u12, a1h, a1l, b2h, b2l) GLF_M16_TILE(t13, u13, a1h, a1l, b3h, b3l)             \
+            GLF_H8_PIECE(2, wr, CONV_, LOAD_)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if (NEXT_) { GLF_M16_A(nxt, 0, a0h, a0l) GLF_M16_A(nxt, 1, a1h, a1l) }                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_M16_TILE(t20, u20, a2h, a2l, b0h, b0l) GLF_M16_TILE(t30, u30, a3h, a3l, b0h, b0l)             \
+            if (NEXT_) GLF_M16_B(nxt, 0, b0h, b0l)                                                            \
+            GLF_H8_PIECE(3, wr, CONV_, LOAD_)                                                                 \
+            GLF_M16_TILE(t21, u21, a2h, a2l, b1h, b1l) GLF_M16_TILE(t31, u31, a3h, a3l, b1h, b1l)             \
+            if (NEXT_) GLF_M16_B(nxt, 1, b1h, b1l)                                                            \
+            GLF_H8_PIECE(4, wr, CONV_, LOAD_)                                                                 \
+            GLF_M16_TILE(t22, u22, a2h, a2l, b2h, b2l) GLF_M16_TILE(t32, u32, a3h, a3l, b2h, b2l)             \
+            if (NEXT_) GLF_M16_B(nxt, 2, b2h, b2l)                                                            \
+            GLF_H8_PIECE(5, wr, CONV_, LOAD_)                                                                 \
+            GLF_M16_TILE(t23, u23, a2h, a2l, b3h, b3l) GLF_M16_TILE(t33, u33, a3h, a3l, b3h, b3l)             \
+            if (NEXT_) GLF_M16_B(nxt, 3, b3h, b3l)                                                            \
+            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            __syncthreads();                                                                                  \
+        }
+        int it = 0;
+        for (; it + 3 < ntiles; ++it) GLF_M16_BODY(true, true, true)
+        if (it + 2 < ntiles) { GLF_M16_BODY(true, false, true) ++it; }
+        if (it + 1 < ntiles) { GLF_M16_BODY(false, false, true) ++it; }
+        GLF_M16_BODY(false, false, false)
+    }
+
+    float cmax = 0.f;
+    const bool p_colstats = args.colstats != nullptr;
+    // one result element -> C (plain / accumulate / region store, or the atomic of per-tap rectangles); cs / cq: the calling
+    // lane's column sum and sum of squares over the elements it stores (colstats)
+    auto put = [&](float a, int row, int col, float bv, double& cs, double& cq) __attribute__((always_inline)) {
+        if (row >= pMe) return;
+        long long orow = row;
+        if (p_rect) {
+            const int hw = r_h * r_w;
+            const int n = row / hw, rem = row - n * hw;
+            const int yy = rem / r_w;
+            orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+            if (p_rect == 1) { atomicAdd(C + orow * p_ldc + col, p_alpha * a); return; }
+        }
+        float* dst = C + orow * p_ldc + col;
+        float v = p_alpha * a + bv;
+        if (p_accumulate) v += *dst;
+        *dst = v;
+        cmax = fmaxf(cmax, fabsf(v));
+        if (p_colstats) { const double vd = (double)v; cs += vd; cq = fma(vd, vd, cq); }
     };
-    // in double from the first product on: E[x^2] - E[x]^2 cancels badly when a channel's values are close together (the
-    // ASPP pooled branch: N nearly equal frame averages), fp32 partial sums cost 4e-4 on its BatchNorm output there
-    double cs0 = 0.0, cq0 = 0.0, cs1 = 0.0, cq1 = 0.0;
-    emit(c00 + m00 * 0x1p-11f, 0, 0, cs0, cq0); emit(c01 + m01 * 0x1p-11f, 0, 1, cs1, cq1);
-    emit(c10 + m10 * 0x1p-11f, 1, 0, cs0, cq0); emit(c11 + m11 * 0x1p-11f, 1, 1, cs1, cq1);
+    // column statistics in double from the first product on: E[x^2] - E[x]^2 cancels badly when a channel's values are close
+    // together (the ASPP pooled branch: N nearly equal frame averages), fp32 partial sums cost 4e-4 on its BatchNorm output
+    if (!M16) {
+        const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+        auto emit = [&](const f32x16& acc, int ti, int tj, double& cs, double& cq) {
+            const int col = tn * BN + wn + 32 * tj + col_l;
+            if (col >= pN) return;
+            const float bv = p_bias ? p_bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) put(acc[r], tm * BM8 + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l, col, bv, cs, cq);
+        };
+        double cs0 = 0.0, cq0 = 0.0, cs1 = 0.0, cq1 = 0.0;
+        emit(c00 + m00 * 0x1p-11f, 0, 0, cs0, cq0); emit(c01 + m01 * 0x1p-11f, 0, 1, cs1, cq1);
+        emit(c10 + m10 * 0x1p-11f, 1, 0, cs0, cq0); emit(c11 + m11 * 0x1p-11f, 1, 1, cs1, cq1);
+        if (args.colstats && p_rect != 1) {
+            // lanes l and l + 32 hold the two row groups of the same column: fold them, then one f64 atomic per column
+            // and statistic from this wave's 64 rows
+            double* st = args.colstats;
+            cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
+            cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
+            if (lane < 32) {
+                const int col0 = tn * BN + wn + col_l, col1 = col0 + 32;
+                if (col0 < pN) { atomicAdd(st + col0, cs0); atomicAdd(st + pN + col0, cq0); }
+                if (col1 < pN) { atomicAdd(st + col1, cs1); atomicAdd(st + pN + col1, cq1); }
+            }
+        }
+    } else {
+        // 16 x 16 tiles: element r of tile (i, j) is row 16 i + 4 (lane >> 4) + r, column 16 j + (lane & 15)
+        const int col_l = lane & 15, row_l = 4 * (lane >> 4);
+        double cs[4] = {0.0, 0.0, 0.0, 0.0}, cq[4] = {0.0, 0.0, 0.0, 0.0};
+        auto emit16 = [&](const f32x4& acc, int ti, int tj) {
+            const int col = tn * BN + wn + 16 * tj + col_l;
+            if (col >= pN) return;
+            const float bv = p_bias ? p_bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put(acc[r], tm * BM8 + wm + 16 * ti + row_l + r, col, bv, cs[tj], cq[tj]);
+        };
+        emit16(t00 + u00 * 0x1p-11f, 0, 0); emit16(t01 + u01 * 0x1p-11f, 0, 1); emit16(t02 + u02 * 0x1p-11f, 0, 2); emit16(t03 + u03 * 0x1p-11f, 0, 3);
+        emit16(t10 + u10 * 0x1p-11f, 1, 0); emit16(t11 + u11 * 0x1p-11f, 1, 1); emit16(t12 + u12 * 0x1p-11f, 1, 2); emit16(t13 + u13 * 0x1p-11f, 1, 3);
+        emit16(t20 + u20 * 0x1p-11f, 2, 0); emit16(t21 + u21 * 0x1p-11f, 2, 1); emit16(t22 + u22 * 0x1p-11f, 2, 2); emit16(t23 + u23 * 0x1p-11f, 2, 3);
+        emit16(t30 + u30 * 0x1p-11f, 3, 0); emit16(t31 + u31 * 0x1p-11f, 3, 1); emit16(t32 + u32 * 0x1p-11f, 3, 2); emit16(t33 + u33 * 0x1p-11f, 3, 3);
+        if (args.colstats && p_rect != 1) {
+            double* st = args.colstats;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {               // the four row groups of a column sit in lanes l, l + 16, l + 32, l + 48
+                cs[j] += __shfl_xor(cs[j], 16, 64); cq[j] += __shfl_xor(cq[j], 16, 64);
+                cs[j] += __shfl_xor(cs[j], 32, 64); cq[j] += __shfl_xor(cq[j], 32, 64);
+                const int col = tn * BN + wn + 16 * j + col_l;
+                if (lane < 16 && col < pN) { atomicAdd(st + col, cs[j]); atomicAdd(st + pN + col, cq[j]); }
+            }
+        }
+    }
     if (args.amax_c && p_rect != 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
-    }
-    if (args.colstats && p_rect != 1) {
-        // lanes l and l + 32 hold the two row groups of the same column: fold them, then one f64 atomic per column
-        // and statistic from this wave's 64 rows
-        double* st = args.colstats;
-        cs0 += __shfl_xor(cs0, 32, 64); cq0 += __shfl_xor(cq0, 32, 64);
-        cs1 += __shfl_xor(cs1, 32, 64); cq1 += __shfl_xor(cq1, 32, 64);
-        if (lane < 32) {
-            const int col0 = tn * BN + wn + col_l, col1 = col0 + 32;
-            if (col0 < pN) { atomicAdd(st + col0, cs0); atomicAdd(st + pN + col0, cq0); }
-            if (col1 < pN) { atomicAdd(st + col1, cs1); atomicAdd(st + pN + col1, cq1); }
-        }
     }
 }
 
@@ -840,14 +982,18 @@ int init_gemm_f16s_attrs() {
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_tn_f16s_kernel<false, 3>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s_kernel<true, 3>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s8_kernel<false, 3>), SMEM_TN_H8)
     SET_ATTR((gemm_tn_f16s8_kernel<true, 3>), SMEM_TN_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false>), SMEM_ROWS_H8)
     SET_ATTR((gemm_tn_f16s_kernel<false, 1>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s_kernel<true, 1>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s8_kernel<false, 1>), SMEM_TN_H8)
@@ -888,13 +1034,19 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     }
     a.tiles_m = (int)tiles_m;
     dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
+    static const bool m16 = [] { const char* e = getenv("GLF_MFMA16"); return e ? e[0] != '0' : GLF_MFMA16_DEFAULT; }();
+    static const int prio = [] { const char* e = getenv("GLF_SETPRIO"); return e ? (e[0] != '0') : GLF_SETPRIO_DEFAULT; }();
+    static const int group_m = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : GLF_GROUP_M_DEFAULT; }();
+    a.flags = prio | ((group_m & 0xff) << 8);
+#define GLF_LAUNCH_ROWS(G, NP_, M_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, M_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
     if (nprod == 3) {
-        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 3, true); else GLF_LAUNCH_ROWS(false, 3, true); }
+        else { if (gather) GLF_LAUNCH_ROWS(true, 3, false); else GLF_LAUNCH_ROWS(false, 3, false); }
     } else {
-        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 1>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 1>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 1, true); else GLF_LAUNCH_ROWS(false, 1, true); }
+        else { if (gather) GLF_LAUNCH_ROWS(true, 1, false); else GLF_LAUNCH_ROWS(false, 1, false); }
     }
+#undef GLF_LAUNCH_ROWS
     return check_launch("gemm_nt(f16x3, 256x128)");
 }
 
