@@ -43,6 +43,20 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldy", C.c_int64), ("lddy", C.c_int64), ("ldd", C.c_int64)]
 
 
+class ConvParams(C.Structure):
+    """Mirror of glf_conv_params (include/glfusion.h)."""
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32), ("precision", C.c_int32),
+                ("amax_x", C.c_void_p), ("amax_w", C.c_void_p), ("amax_dy", C.c_void_p), ("amax_out", C.c_void_p), ("colstats", C.c_void_p)]
+
+
+class ConvPlan(C.Structure):
+    """Mirror of glf_conv_plan (include/glfusion.h)."""
+    _fields_ = [("ho", C.c_int32), ("wo", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("taps", C.c_int32),
+                ("kept_taps", C.c_int32), ("tap_mask", C.c_uint32), ("plain", C.c_int32), ("rect", C.c_int32), ("split", C.c_int32),
+                ("zero_fill", C.c_int32), ("colstats_ok", C.c_int32), ("workspace_bytes", C.c_int64)]
+
+
 _SCALARS = {
     "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
     "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None,
@@ -57,6 +71,10 @@ def _ctype(decl: str):
         return C.POINTER(GemmParams)
     if "glf_attn_params" in decl:
         return C.POINTER(AttnParams)
+    if "glf_conv_params" in decl:
+        return C.POINTER(ConvParams)
+    if "glf_conv_plan" in decl:
+        return C.POINTER(ConvPlan)
     if "*" in decl:
         return C.c_void_p
     t = decl.replace("const", "").split()

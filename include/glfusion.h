@@ -155,6 +155,46 @@ int glf_gemm_tn(const float* A, const float* B, float* C,
 size_t glf_gemm_tn_workspace_bytes(const glf_gemm_params* p);
 
 /* ---------------------------------------------------------------------------------------
+ * Convolution entry points (F.conv2d forward / backward: models/_utils.py:192 excluded -- glf_stem7x7_* --,
+ * torchvision Bottleneck convs at ours.py:1797-1800, deeplabv3.py:104-165).  x [n][h][w][cin] and y / dy
+ * [n][ho][wo][cout] channels-last, weights tap-major [kh*kw][cout][cin] (glf_oihw_to_tap_major), groups = 1, zero
+ * padding.  They sit on top of glf_gemm_* and embed its launch policy (host-side tap mask of the taps that can touch
+ * the map at all, per-tap rectangle / region modes when most tap work would be padding -- the ASPP rates on a 28 x 28
+ * map --, split-K of the weight gradient, zero fills), so a C caller needs nothing but this block.
+ * glf_conv2d_plan reports what a pass will do (GEMM extents, kept taps, mode, slices, workspace) without launching.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, h, w, cin, cout, kh, kw, stride, pad, dil;
+    int32_t precision;          /* as glf_gemm_params.precision (0 = process default)                            */
+    const float* amax_x;        /* precision 3 / 4, optional: device scalars bounding max|x|, max|w|, max|dy|     */
+    const float* amax_w;        /* (NULL: measured by the library)                                               */
+    const float* amax_dy;
+    float* amax_out;            /* optional: receives max|output| of fwd / dgrad where the kernel stores directly */
+    double* colstats;           /* fwd only, optional: [2][cout] zero-filled doubles, += column sums of y, y^2    */
+} glf_conv_params;
+typedef struct {
+    int32_t ho, wo;             /* output map                                                                     */
+    int32_t M, N, K;            /* per-tap GEMM extents of the pass                                               */
+    int32_t taps, kept_taps;    /* kh*kw and how many of them can be in range                                     */
+    uint32_t tap_mask;
+    int32_t plain;              /* 1: a 1x1 stride-1 conv = plain GEMM                                            */
+    int32_t rect;               /* 0 dense, 1 per-tap rectangles (atomics into a zero-filled output), 2 regions   */
+    int32_t split;              /* wgrad: reduction slices                                                        */
+    int32_t zero_fill;          /* the call zero-fills its output first                                           */
+    int32_t colstats_ok;        /* fwd: glf_conv_params.colstats can be honoured                                  */
+    int64_t workspace_bytes;    /* wgrad: scratch for the two-stage split-K reduction (0: none needed)            */
+} glf_conv_plan;
+int glf_conv2d_plan(const glf_conv_params* p, int pass /* 0 fwd, 1 dgrad, 2 wgrad */, glf_conv_plan* plan);
+int glf_conv2d_fwd(const float* x, const float* w_tap, const float* bias, float* y, const glf_conv_params* p, glf_stream_t s);
+/* w_tap_t: the same weights as [tap][cin][cout] (glf_oihw_to_tap_major_t); needed by the split-precision kernels,
+ * may be NULL for exact fp32 (then w_tap is used). */
+int glf_conv2d_dgrad(const float* dy, const float* w_tap, const float* w_tap_t, float* dx, const glf_conv_params* p, glf_stream_t s);
+/* dw_tap [kh*kw][cout][cin].  workspace (>= plan.workspace_bytes, may be NULL: float atomics instead of the two-stage
+ * reduction) is caller-owned scratch. */
+int glf_conv2d_wgrad(const float* dy, const float* x, float* dw_tap, float* workspace, int64_t workspace_bytes,
+                     const glf_conv_params* p, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
  * Fused softmax attention of TPAVIModule's `embedded` mode (ours.py:881, 896-897, 902):
  *   y[n] = softmax(theta[n] phi[n]^T, dim = -1) g[n]      per frame n, theta / phi / g: [L][Ci] rows (row strides ld*).
  * One kernel per pass; the [L][L] score matrix is never written to memory (online row max / sum over 64-key tiles

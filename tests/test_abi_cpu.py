@@ -86,3 +86,57 @@ def test_adam_pointer_table_chunks():
     assert rows.tolist() == [[1000, 2000, 3000, 4000, optim.CHUNK],
                              [1000 + 4 * optim.CHUNK, 2000 + 4 * optim.CHUNK, 3000 + 4 * optim.CHUNK, 4000 + 4 * optim.CHUNK, 7],
                              [16, 32, 48, 64, 5]]
+
+
+def test_conv_plan_matches_host_policy():
+    """glf_conv2d_plan (the launch policy embedded in the C convolution entry points) against the policy the Python autograd
+    wrappers use (ops.tap_mask / rect_fraction / region_mode / _tn_split): same kept taps, same mode, same reduction slices, for
+    every conv geometry of the model (and a few ragged ones) under every precision.  No GPU needed: the plan launches nothing."""
+    import ctypes as C
+    from glfusion_amd import ops
+    from glfusion_amd._lib import ConvParams, ConvPlan, lib
+    convs = [  # n, h, w, cin, cout, k, stride, pad, dil
+        (64, 55, 55, 64, 64, 3, 1, 1, 1), (64, 55, 55, 128, 128, 3, 2, 1, 1), (64, 55, 55, 256, 512, 1, 2, 0, 1),
+        (64, 28, 28, 256, 256, 3, 1, 2, 2), (64, 28, 28, 512, 512, 3, 1, 4, 4), (64, 28, 28, 2048, 256, 3, 1, 12, 12),
+        (64, 28, 28, 2048, 256, 3, 1, 24, 24), (64, 28, 28, 2048, 256, 3, 1, 36, 36), (64, 28, 28, 2048, 256, 1, 1, 0, 1),
+        (64, 28, 28, 256, 5, 1, 1, 0, 1), (64, 1, 1, 2048, 256, 1, 1, 0, 1), (32, 56, 56, 2048, 256, 3, 1, 36, 36),
+        (3, 15, 13, 32, 40, 3, 1, 1, 1), (2, 28, 28, 64, 288, 3, 1, 12, 12), (192, 28, 28, 1024, 2048, 1, 1, 0, 1)]
+    for prec in ("f32", "bf16x6", "f16x3", "f16"):
+        ops.set_precision(prec)
+        try:
+            for (n, h, w, cin, cout, k, stride, pad, dil) in convs:
+                p = ConvParams()
+                p.n, p.h, p.w, p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil = n, h, w, cin, cout, k, k, stride, pad, dil
+                p.precision = ops.PRECISIONS.index(prec) + 1
+                ho, wo = ops._conv_out(h, k, stride, pad, dil), ops._conv_out(w, k, stride, pad, dil)
+                taps, plain = k * k, (k == 1 and stride == 1 and pad == 0)
+                pl = ConvPlan()
+                # forward
+                assert lib.glf_conv2d_plan(C.byref(p), 0, C.byref(pl)) == 0
+                mask = 1 if plain else ops.tap_mask(1, ho, wo, h, w, k, k, stride, pad, dil)
+                rect = (not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1
+                        and ops.rect_fraction(1, ho, wo, h, w, k, k, pad, dil, mask) < ops._rect_thr("fwd"))
+                assert (pl.ho, pl.wo, pl.tap_mask, pl.rect, pl.plain) == (ho, wo, mask, int(rect), int(plain)), (prec, "fwd", n, h, cin, cout, k, dil)
+                from torch import empty
+                wshape = empty(cout, cin, k, k, device="meta")
+                assert bool(pl.colstats_ok) == ops.conv_stats_fusable(wshape, stride, pad, dil, h, w), (prec, "colstats", cin, cout, k, dil)
+                # dgrad
+                assert lib.glf_conv2d_plan(C.byref(p), 1, C.byref(pl)) == 0
+                mask = 1 if plain else ops.tap_mask(2, h, w, ho, wo, k, k, stride, pad, dil)
+                frac = 1.0 if plain or stride != 1 else ops.rect_fraction(2, h, w, ho, wo, k, k, pad, dil, mask)
+                if mask and not plain and bin(mask).count("1") > 1 and ops.region_mode(taps, k, stride, pad, dil, ho, wo, h, w, cout, frac):
+                    want = 2
+                else:
+                    want = int(not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1 and frac < ops._rect_thr("dgrad"))
+                assert (pl.tap_mask, pl.rect) == (mask, want), (prec, "dgrad", n, h, cin, cout, k, dil)
+                # wgrad
+                assert lib.glf_conv2d_plan(C.byref(p), 2, C.byref(pl)) == 0
+                mask = 1 if plain else ops.tap_mask(1, ho, wo, h, w, k, k, stride, pad, dil)
+                ntap = bin(mask).count("1")
+                rect = (not plain and taps > 1 and stride == 1 and ntap > 1
+                        and ops.rect_fraction(1, ho, wo, h, w, k, k, pad, dil, mask) < ops._rect_thr("wgrad"))
+                frac = ops.rect_fraction(1, ho, wo, h, w, k, k, pad, dil, mask) if rect else 1.0
+                split = ops._tn_split(max(512, int(n * ho * wo * frac)), cout, cin, ntap)
+                assert (pl.tap_mask, pl.rect, pl.split) == (mask, int(rect), split), (prec, "wgrad", n, h, cin, cout, k, dil, pl.split, split)
+        finally:
+            ops.set_precision("f32")

@@ -534,3 +534,45 @@ def test_fused_softmax_matches_materialised_path():
     for k, gk in res[False][2].items():
         if float(gk.norm()) > 1e-5 * top:                      # W_z.0.bias, g.bias: exactly-zero true gradients (a constant
             assert _rel_l2(res[True][2][k], gk) <= 1e-4, k     # shift in front of a train-mode BatchNorm): rounding noise only
+
+
+# ------------------------------------------------------------------------------------------ C convolution entry points
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 96, 1, 1, 0, 1), (2, 55, 55, 16, 24, 3, 2, 1, 1), (2, 28, 28, 64, 32, 3, 1, 12, 12),
+                                 (2, 28, 28, 64, 32, 3, 1, 24, 24), (2, 28, 28, 64, 32, 3, 1, 36, 36), (2, 28, 28, 32, 160, 3, 1, 2, 2)])
+def test_conv2d_c_entry_points_match_autograd_path(ops, cfg):
+    """glf_conv2d_{fwd,dgrad,wgrad} called the way a C host would (tap-major weights, one parameter block, no policy on the
+    caller's side) against ops.conv2d + autograd, which drives glf_gemm_* with the host-side policy: same results (1e-6
+    relative L2: per-tap rectangle modes sum with atomics in either path)."""
+    import ctypes as C
+    from glfusion_amd._lib import ConvParams, ConvPlan, check, lib
+    n, h, w, cin, cout, k, stride, pad, dil = cfg
+    x = rnd(n, h, w, cin, seed=50).to(DEV).requires_grad_(True)
+    wt = (rnd(cout, cin, k, k, seed=51) / np.sqrt(cin * k * k)).to(DEV).requires_grad_(True)
+    y = ops.conv2d(x, wt, None, stride, pad, dil)
+    gy = rnd(*y.shape, seed=52).to(DEV)
+    y.backward(gy)
+    p = ConvParams()
+    p.n, p.h, p.w, p.cin, p.cout, p.kh, p.kw, p.stride, p.pad, p.dil = n, h, w, cin, cout, k, k, stride, pad, dil
+    p.precision = ops.PRECISIONS.index(ops.get_precision()) + 1
+    pl = ConvPlan()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w_tap = torch.empty(k * k, cout, cin, device=DEV)
+    w_tap_t = torch.empty(k * k, cin, cout, device=DEV)
+    check(lib.glf_oihw_to_tap_major(ptr(wt.detach().contiguous()), ptr(w_tap), cout, cin, k * k, s), "tap_major")
+    check(lib.glf_oihw_to_tap_major_t(ptr(wt.detach().contiguous()), ptr(w_tap_t), cout, cin, k * k, s), "tap_major_t")
+    check(lib.glf_conv2d_plan(C.byref(p), 0, C.byref(pl)), "plan")
+    y2 = torch.full((n, pl.ho, pl.wo, cout), float("nan"), device=DEV)
+    check(lib.glf_conv2d_fwd(ptr(x.detach()), ptr(w_tap), None, ptr(y2), C.byref(p), s), "conv2d_fwd")
+    dx2 = torch.full((n, h, w, cin), float("nan"), device=DEV)
+    check(lib.glf_conv2d_dgrad(ptr(gy), ptr(w_tap), ptr(w_tap_t), ptr(dx2), C.byref(p), s), "conv2d_dgrad")
+    check(lib.glf_conv2d_plan(C.byref(p), 2, C.byref(pl)), "plan")
+    ws = torch.empty(max(int(pl.workspace_bytes) // 4, 1), device=DEV)
+    dwt = torch.full((k * k, cout, cin), float("nan"), device=DEV)
+    check(lib.glf_conv2d_wgrad(ptr(gy), ptr(x.detach()), ptr(dwt), ptr(ws), int(pl.workspace_bytes), C.byref(p), s), "conv2d_wgrad")
+    dw2 = dwt.permute(1, 2, 0).reshape(cout, cin, k, k)
+    assert _rel_l2(y2, y) <= 1e-6 and _rel_l2(dx2, x.grad) <= 1e-6 and _rel_l2(dw2, wt.grad) <= 1e-6
+    # without a workspace the slices meet in atomics: same numbers up to summation order
+    dwt2 = torch.full((k * k, cout, cin), float("nan"), device=DEV)
+    check(lib.glf_conv2d_wgrad(ptr(gy), ptr(x.detach()), ptr(dwt2), None, 0, C.byref(p), s), "conv2d_wgrad(atomics)")
+    assert _rel_l2(dwt2, dwt) <= 1e-6
