@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
+    ap.add_argument("--no-config3", action="store_true", help="skip the fp16-arithmetic leg (BASELINE.json configs[2])")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -310,6 +311,8 @@ def main():
     main_leg = run_leg(args.precision)
     # second leg with the SAME --steps / --warmup: the strictly-fp32 step (v_mfma_f32_32x32x2_f32 everywhere), its own roofline
     exact_leg = run_leg("f32") if (args.precision != "f32" and not args.no_exact_f32) else None
+    # third leg, same --steps / --warmup: BASELINE.json configs[2] (16-bit MFMA arithmetic): fp16 operands, one MFMA per product
+    c3_leg = run_leg("f16") if (args.precision == "f16x3" and not args.no_config3) else None
     ops.set_precision(args.precision)
 
     # secondary figure (outside the metric, which excludes the optimizer): the fused Adam step over
@@ -365,6 +368,14 @@ def main():
                                 "dtype": "f32", "loss": exact_leg["loss"],
                                 "arithmetic": "v_mfma_f32_32x32x2_f32 (exact fp32) for every contraction, same step, same --steps / --warmup",
                                 "roofline": roofline_of(exact_leg)}
+        if c3_leg is not None:
+            out["config3_f16"] = {"value": round(args.clips * world * args.steps / c3_leg["dt"], 4), "unit": "clips/s",
+                                  "ms_per_step": round(c3_leg["dt"] / args.steps * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
+                                  "dtype": "f16 operands / fp32 accumulate / fp32 storage", "loss": c3_leg["loss"],
+                                  "note": "BASELINE.json configs[2]: the same step with every contraction operand rounded to fp16 (per-tensor "
+                                          "power-of-two scale), ONE v_mfma_f32_32x32x16_f16 per product; not fp32-equivalent (tolerances: "
+                                          "tests/test_gpu_model.py::test_f16_mode_parity); activations stay fp32 in HBM",
+                                  "roofline": roofline_of(c3_leg)}
         out["optimizer_step"] = optimizer_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

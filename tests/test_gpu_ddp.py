@@ -163,7 +163,7 @@ def test_bench_self_launch_two_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "1",
-                          "--no-exact-f32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--no-exact-f32", "--no-config3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_collective"] == 2
