@@ -325,6 +325,25 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         GLF_H8_FRAGS(f, 0, fo0)
         int cur = 0, nxt = 1, wr = 2;           // LDS buffers of tile it, it+1, it+2
         // CONV_/LOAD_/NEXT_ are compile-time constants: the steady-state body is straight-line code
+// GLF_SGB: ask the machine scheduler for an even interleave -- one MFMA, then ~five VALU instructions of the conversion
+// pieces (an MFMA keeps the SIMD's vector issue for 8 of its 32 cycles: ~24 cycles = 5-6 plain VALU fit behind each) --
+// instead of the bursts it picks by itself (five MFMAs back to back, then 9-12 VALU with the matrix pipe idle).
+#ifndef GLF_SGB
+#define GLF_SGB 0
+#endif
+#if GLF_SGB
+#define GLF_SGB_HALF()                                                                                        \
+            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                \
+                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                            \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+                    __builtin_amdgcn_sched_group_barrier(0x002, GLF_SGB, 0);                                  \
+                }                                                                                             \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
+            }
+#else
+#define GLF_SGB_HALF()
+#endif
 #define GLF_H8_BODY(CONV_, LOAD_, NEXT_)                                                                      \
         {                                                                                                     \
             if (LOAD_) advance();                                                                             \
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             GLF_H8_PIECE(1, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
             GLF_H8_PIECE(2, wr, CONV_, LOAD_)                                                                 \
+            GLF_SGB_HALF()                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             if (NEXT_) GLF_H8_FRAGS(f, nxt, fo0)                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -344,6 +364,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             GLF_H8_PIECE(4, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
             GLF_H8_PIECE(5, wr, CONV_, LOAD_)                                                                 \
+            GLF_SGB_HALF()                                                                                    \
             { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
             __syncthreads();                                                                                  \
         }

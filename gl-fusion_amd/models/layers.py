@@ -91,6 +91,6 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
     if training and FUSE_BN_STATS and not (conv.in_channels == 1 and conv.kernel_size == (7, 7)):
         stride, pad, dil = conv._geom()
         if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2]):
-            sums = ops.zeros(2, conv.out_channels, dtype=torch.float64, device=x.device)
+            sums = ops.stats_slot(conv.out_channels, x.device)
             return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums)
     return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual)

@@ -240,6 +240,24 @@ def amax_slot(dev) -> Optional[torch.Tensor]:
     return pool[0][i:i + 1]
 
 
+_stats_pool = {}
+_STATS_POOL_DOUBLES = 1 << 19
+
+
+def stats_slot(c: int, dev) -> torch.Tensor:
+    """A zeroed float64 [2, c] for a contraction's fused column statistics (glf_gemm_params.colstats), carved out of a
+    per-stream pool that is zeroed in bulk (one fill per ~500 k doubles instead of one tiny fill per conv); a used-up pool
+    stays alive through the slices that reference it."""
+    key = torch.cuda.current_stream().cuda_stream
+    need = 2 * c
+    pool = _stats_pool.get(key)
+    if pool is None or pool[1] + need > pool[0].numel() or pool[0].device != dev:
+        pool = _stats_pool[key] = [zeros(max(_STATS_POOL_DOUBLES, need), dtype=torch.float64, device=dev), 0]
+    i = pool[1]
+    pool[1] = i + need
+    return pool[0][i:i + need].view(2, c)
+
+
 def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
     """Attach a maximum produced as a by-product of the kernel that wrote t."""
     if amax is not None:
