@@ -62,11 +62,14 @@ def pmc_traffic_per_launch(kernel: str, precision: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
     profiles/summarize_pmc.py) -- PMC counters cannot be collected inside this process, so the figure is the one
     measured on the same workload when the profile was taken; None if the profile is missing."""
-    path = os.path.join(ROOT, "profiles", f"r01_bench_c2_{precision}_pmc_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", f"r02_bench_c2_{precision}_pmc_hbm_traffic.csv")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r01_bench_c2_{precision}_pmc_hbm_traffic.csv")
     try:
         for line in open(path).read().splitlines()[1:]:
             name, rest = line.rsplit(",", 5)[0], line.rsplit(",", 5)[1:]
-            if name.replace(" ", "") == kernel.replace(" ", ""):
+            # profile names carry every template argument ("gemm_rows_f16s8_kernel<false, 3, false>"): match on the leading ones
+            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")):
                 return {"bytes_per_launch": float(rest[4]) * 1e6, "unit": "B", "source": os.path.relpath(path, ROOT)}
     except (OSError, ValueError, IndexError):
         pass
