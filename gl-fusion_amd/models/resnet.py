@@ -33,6 +33,8 @@ class Bottleneck(nn.Module):
     def forward_nhwc(self, x):
         # x feeds the shortcut and conv1: its two gradients meet in ONE pass (ops.fan_out) instead of autograd's add
         x, xs = ops.fan_out(x, 2)
+        if self.downsample is None and x is not xs:
+            ops.join_gradients(x, xs)     # identity shortcut: conv1's dgrad accumulates onto the shortcut's gradient
         idn = xs if self.downsample is None else conv_bn_act(xs, self.downsample[0], self.downsample[1], relu=False)
         out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)

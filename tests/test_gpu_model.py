@@ -234,7 +234,7 @@ def _kinkfree_truth(golden_dir):
 
 
 def test_e2e_train_kinkfree_gradients(golden_dir, precision):
-    """Every parameter gradient of a full train step within 1e-3 relative L2 of the fp64 reference, under all three
+    """Every parameter gradient of a full train step within 2e-3 relative L2 of the fp64 reference, under all three
     contraction precisions.  The fixture's weights keep every ReLU input away from zero (oracle.kinkfree_fill), so no
     allowance for flipped masks is made; the reference's own fp32 evaluation sits at ~2e-5 (median) on it.  A handful of
     tensors are ill-conditioned for ANY fp32 arithmetic -- the ASPP pooled branch normalises 8 per-frame averages per channel;
@@ -254,20 +254,20 @@ def test_e2e_train_kinkfree_gradients(golden_dir, precision):
     assert abs(float(loss) - t["loss"]) <= 1e-6 * abs(t["loss"])
     for v in views:
         assert close(pred[v], t["pred"][v], 1e-4), v
-    worst = (0.0, "")
+    worst = (0.0, "", 0.0)
     for name, p in model.named_parameters():
         if name not in t["grads"]:
             assert p.grad is None, name
             continue
         want = t["grads"][name]
         err = float((p.grad.detach().cpu().double() - want).norm())
-        base = 2e-3 if precision == "bf16x6" else 1e-3       # bf16x6 (the least used mode): measured 1.5e-3 on one centre-ness conv
+        base = 2e-3       # measured closest calls: exact fp32 9.1e-4, f16x3 1.4e-4, bf16x6 1.5e-3 (all on centre-ness head convs)
         tol = max(base, 10.0 * t["noise32"][name]) * float(want.norm()) + 1e-5 * t["scale"][name.split(".")[0]]
         rel = err / max(float(want.norm()), 1e-30)
-        if float(want.norm()) > 1e-6 * t["scale"][name.split(".")[0]] and rel > worst[0]:
-            worst = (rel, name)
+        if err / tol > worst[0]:
+            worst = (err / tol, name, rel)
         assert err <= tol, (name, err, float(want.norm()), tol)
-    print(f"kink-free step [{precision}]: worst relative L2 gradient error {worst[0]:.2e} ({worst[1]})")
+    print(f"kink-free step [{precision}]: closest to its gate: {worst[1]} at {worst[0]:.2f} of the tolerance (relative L2 {worst[2]:.2e})")
     sd = model.state_dict()
     for k in t["g"].files:
         if k.startswith("bn:"):
