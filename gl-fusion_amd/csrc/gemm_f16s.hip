@@ -101,7 +101,10 @@ constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 // chip holds a higher clock on the smaller shape (MI355X_MICROARCH.md, DVFS item 7).  LDS rows keep their 64-byte
 // layout; only the 16-byte chunk swizzle differs (chunk g(c) ^ (row >> 2 & 3), g = 0,3,1,2: conflict-free ds_read_b128 for
 // the lane -> (row = lane & 15, chunk = lane >> 4) fragment map).
-template <bool GATHER, int NP, bool M16>
+// BP: the B operand (weights) arrives PRE-SPLIT: two fp16 planes h, l (same element indexing as the fp32 operand, made
+// once per weight update by glf_split_f16_planes with the scale of args.amax_b); its staging is then two 8-byte loads and
+// two LDS stores per piece, no conversion (a third of the kernel's split arithmetic gone).
+template <bool GATHER, int NP, bool M16, bool BP>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -176,7 +179,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     }
     const int bz = blockIdx.z;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
-    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
+    // BP: B addresses the h plane in units of floats (= 2 halves); the l plane sits b_delta floats further
+    const float* __restrict__ B = BP ? reinterpret_cast<const float*>(args.Bh) + (((long long)bz * p_bsb) >> 1) : p_B + (long long)bz * p_bsb;
+    const long long b_delta = BP ? (reinterpret_cast<const float*>(args.Bl) - reinterpret_cast<const float*>(args.Bh)) : 0;
     float* __restrict__ C = p_C + (long long)bz * p_bsc;
 
     const int ac = tid & 7, ar = tid >> 3;              // 8 float4 per 32-deep row; rows ar + 64 j
@@ -243,17 +248,26 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                 }
                 pa[j] = (off >= 0 ? A + off : p_zero) + 4 * ac;          // padding / overhang rows read the zero page
             }
-            const float* Bt = B + (long long)tap * p_tsb;
+            if (BP) {
+                const float* Bt = B + (((long long)tap * p_tsb) >> 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = tn * BN + ar + 64 * j;
-                pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + 4 * ac;
+                for (int j = 0; j < 2; ++j) {
+                    const int n = min(tn * BN + ar + 64 * j, pN - 1);      // overhang rows repeat the last one: their columns are never stored
+                    pb[j] = Bt + (((long long)n * p_ldb) >> 1) + 2 * ac;
+                }
+            } else {
+                const float* Bt = B + (long long)tap * p_tsb;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = tn * BN + ar + 64 * j;
+                    pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + 4 * ac;
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pa[j] += BK;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pb[j] += BK;
+            for (int j = 0; j < 2; ++j) pb[j] += BP ? BK / 2 : BK;
         }
     };
     // swizzled staging offset of this thread inside a 64-byte row: 16-byte chunk (ac>>1) ^ ((row>>2)&3), half ac&1
@@ -267,9 +281,25 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     }
 #define GLF_H8_CONV_B(J, buf_)                                                                               \
     {                                                                                                        \
-        const SplitH s = split4h(rb[J], sc_b);                                                               \
         unsigned char* d = smem_s + (buf_) * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64;                        \
-        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;         \
+        if (BP) {                                                                                            \
+            *reinterpret_cast<float2*>(d) = make_float2(rb[J].x, rb[J].y);                                   \
+            if (NP == 3) *reinterpret_cast<float2*>(d + PL_B8) = make_float2(rb[J].z, rb[J].w);              \
+        } else {                                                                                             \
+            const SplitH s = split4h(rb[J], sc_b);                                                           \
+            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;     \
+        }                                                                                                    \
+    }
+#define GLF_H8_LOAD_B(J)                                                                                     \
+    {                                                                                                        \
+        if (BP) {                                                                                            \
+            const float2 h_ = *reinterpret_cast<const float2*>(pb[J]);                                       \
+            float2 l_ = h_;                                                                                  \
+            if (NP == 3) l_ = *reinterpret_cast<const float2*>(pb[J] + b_delta);                             \
+            rb[J] = make_float4(h_.x, h_.y, l_.x, l_.y);                                                     \
+        } else {                                                                                             \
+            rb[J] = *reinterpret_cast<const float4*>(pb[J]);                                                 \
+        }                                                                                                    \
     }
     // piece pc (0..5): convert + store registers of tile t+1, then refill them with tile t+2
 #define GLF_H8_PIECE(pc, buf_, conv_, load_)                                                                 \
@@ -278,8 +308,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         case 1: if (conv_) GLF_H8_CONV_A(1, buf_) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); break; \
         case 2: if (conv_) GLF_H8_CONV_A(2, buf_) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); break; \
         case 3: if (conv_) GLF_H8_CONV_A(3, buf_) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); break; \
-        case 4: if (conv_) GLF_H8_CONV_B(0, buf_) if (load_) rb[0] = *reinterpret_cast<const float4*>(pb[0]); break; \
-        default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); break; \
+        case 4: if (conv_) GLF_H8_CONV_B(0, buf_) if (load_) GLF_H8_LOAD_B(0) break;                             \
+        default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) GLF_H8_LOAD_B(1) break;                            \
     }
 
     if (!M16 && ntiles > 0) {
@@ -994,27 +1024,53 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
 }
 
+// x -> the two fp16 planes of x * s, s = the power of two pow2_scale() derives from *amax (what the kernels do in their
+// staging path, done once for an operand that is reused: weights)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ x, long long n4, const float* __restrict__ amax,
+                                                           f16x4* __restrict__ h, f16x4* __restrict__ l) {
+    float sc, inv;
+    pow2_scale(amax, sc, inv);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const SplitH s = split4h(x[i], sc);
+        h[i] = s.h;
+        l[i] = s.l;
+    }
+}
+
 }  // namespace
 
 namespace glf {
+
+int launch_split_planes(const float* x, long long n, const float* amax, void* h, void* l, hipStream_t s) {
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, amax,
+                       reinterpret_cast<f16x4*>(h), reinterpret_cast<f16x4*>(l));
+    return check_launch("split_f16_planes");
+}
 
 int init_gemm_f16s_attrs() {
     hipError_t e;
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, true, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, true, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, true, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_tn_f16s_kernel<false, 3>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s_kernel<true, 3>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s8_kernel<false, 3>), SMEM_TN_H8)
     SET_ATTR((gemm_tn_f16s8_kernel<true, 3>), SMEM_TN_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false, false>), SMEM_ROWS_H8)
     SET_ATTR((gemm_tn_f16s_kernel<false, 1>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s_kernel<true, 1>), SMEM_TN_H)
     SET_ATTR((gemm_tn_f16s8_kernel<false, 1>), SMEM_TN_H8)
@@ -1059,13 +1115,16 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     static const int prio = [] { const char* e = getenv("GLF_SETPRIO"); return e ? (e[0] != '0') : GLF_SETPRIO_DEFAULT; }();
     static const int group_m = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : GLF_GROUP_M_DEFAULT; }();
     a.flags = prio | ((group_m & 0xff) << 8);
-#define GLF_LAUNCH_ROWS(G, NP_, M_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, M_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
+#define GLF_LAUNCH_ROWS(G, NP_, M_, BP_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, M_, BP_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
+    const bool bp = a.Bh != nullptr && a.Bl != nullptr;          // pre-split B planes (32x32x16 kernels only)
     if (nprod == 3) {
-        if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 3, true); else GLF_LAUNCH_ROWS(false, 3, true); }
-        else { if (gather) GLF_LAUNCH_ROWS(true, 3, false); else GLF_LAUNCH_ROWS(false, 3, false); }
+        if (bp) { if (gather) GLF_LAUNCH_ROWS(true, 3, false, true); else GLF_LAUNCH_ROWS(false, 3, false, true); }
+        else if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 3, true, false); else GLF_LAUNCH_ROWS(false, 3, true, false); }
+        else { if (gather) GLF_LAUNCH_ROWS(true, 3, false, false); else GLF_LAUNCH_ROWS(false, 3, false, false); }
     } else {
-        if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 1, true); else GLF_LAUNCH_ROWS(false, 1, true); }
-        else { if (gather) GLF_LAUNCH_ROWS(true, 1, false); else GLF_LAUNCH_ROWS(false, 1, false); }
+        if (bp) { if (gather) GLF_LAUNCH_ROWS(true, 1, false, true); else GLF_LAUNCH_ROWS(false, 1, false, true); }
+        else if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 1, true, false); else GLF_LAUNCH_ROWS(false, 1, true, false); }
+        else { if (gather) GLF_LAUNCH_ROWS(true, 1, false, false); else GLF_LAUNCH_ROWS(false, 1, false, false); }
     }
 #undef GLF_LAUNCH_ROWS
     return check_launch("gemm_nt(f16x3, 256x128)");

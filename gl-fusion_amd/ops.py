@@ -146,7 +146,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
          split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
          amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None,
-         colstats: Optional[torch.Tensor] = None) -> None:
+         colstats: Optional[torch.Tensor] = None, b_planes: Optional[torch.Tensor] = None) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
     amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library);
     amax_c: a slot from amax_slot() that receives max|C written| (ignored by rect / split > 1 / non-f16x3 calls -- pass
@@ -163,6 +163,9 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
     p.precision = _PREC[0] + 1
+    if b_planes is not None and mode == "nt" and amax_b is not None and K % 32 == 0:
+        # B (a weight layout) pre-split into fp16 planes [2][numel] with the scale of amax_b: not re-split in every tile
+        p.b_planes_h, p.b_planes_l = _p(b_planes[0]), _p(b_planes[1])
     ws = None
     if mode == "tn" and split > 1 and TWO_STAGE_SPLITK:
         # two-stage reduction: the slices store partial sums, a second kernel adds them in a fixed order -- no atomics, no
@@ -330,6 +333,29 @@ def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.
     return out
 
 
+# Measured (C2 step, A/B in one run): 295.2 ms with pre-split weight planes against 292.5 ms without -- a third of the split
+# arithmetic gone, two 8-byte loads in place of one 16-byte load per piece: the kernel is bound by its load path, not by VALU.  Off.
+W_PLANES = os.environ.get("GLF_WPLANES", "0") != "0"
+_planes_cache = {}
+
+
+def weight_planes(layout: torch.Tensor, owner: torch.Tensor, tag: str, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """fp16 planes [2][numel] (h, l with x * s = h + 2^-11 l, s from `amax`) of a dense weight layout `layout` derived from the
+    parameter `owner` -- the B operand of an NT contraction under the split-fp16 precisions.  Split ONCE per weight update
+    (cached against the owner's version counter and the amax scalar it was scaled with) instead of in every tile of every
+    launch that uses the weight.  None when not applicable (other precisions, odd sizes, GLF_WPLANES=0)."""
+    if not W_PLANES or _PREC[0] < 2 or amax is None or layout.numel() % 4 != 0 or not layout.is_contiguous():
+        return None
+    key = (id(owner), tag)
+    hit = _planes_cache.get(key)
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[3] == layout.data_ptr() and hit[4] is amax:
+        return hit[2]
+    pl = torch.empty(2, layout.numel(), dtype=torch.float16, device=layout.device)
+    check(lib.glf_split_f16_planes(_p(layout), layout.numel(), _p(amax), _p(pl[0]), _p(pl[1]), _stream()), "split_f16_planes")
+    _planes_cache[key] = (weakref.ref(owner, lambda _r, k=key: _planes_cache.pop(k, None)), owner._version, pl, layout.data_ptr(), amax)
+    return pl
+
+
 _wT_cache = {}
 
 
@@ -462,9 +488,10 @@ class Conv2dFn(Function):
             zero_(y)
             if colstats is not None:
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
+        am_w = amax_of(weight)
         gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
-             amax_a=amax_of(x), amax_b=amax_of(weight), colstats=colstats)
+             amax_a=amax_of(x), amax_b=am_w, colstats=colstats, b_planes=weight_planes(wt, weight, "w", am_w))
         ctx.save_for_backward(x, wt)
         ctx.join = getattr(x, "_glf_join", None) if plain else None
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
@@ -504,10 +531,11 @@ class Conv2dFn(Function):
                 if split_mode() and cout % 32 == 0:
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
                     am_dx = amax_slot(dx.device) if acc else None
-                    gemm("nt", dy, tap_major_T(ctx.weight_ref), dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
+                    wT = tap_major_T(ctx.weight_ref)
+                    gemm("nt", dy, wT, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                          taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
                          geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect,
-                         amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx)
+                         amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx, b_planes=weight_planes(wT, ctx.weight_ref, "wT", am_w))
                     if acc:
                         dx._glf_amax = None
                         set_amax(dx, am_dx)            # the maximum of the SUM, from the accumulating epilogue
@@ -584,8 +612,9 @@ class ConvCatFn(Function):
                            and t.data_ptr() == t0.data_ptr() + 4 * o for t, o in zip(xs, offs)))
         if ctx.cat:
             y = torch.empty(*t0.shape[:-1], cout, dtype=torch.float32, device=t0.device)
+            am_w = amax_of(weight)
             gemm("nt", t0, w2, y, M=rows, N=cout, K=ctot, lda=ctot, ldb=ctot, ldc=cout, bias=bias,
-                 amax_a=amax_of(t0), amax_b=amax_of(weight))
+                 amax_a=amax_of(t0), amax_b=am_w, b_planes=weight_planes(w2, weight, "w", am_w))
             ctx.save_for_backward(w2, *xs)
             ctx.wshape = tuple(weight.shape)
             ctx.weight_ref = weight
@@ -628,8 +657,9 @@ class ConvCatFn(Function):
                 dcat = torch.empty(*t0.shape[:-1], ctot, dtype=torch.float32, device=dy.device)
                 am_dc = amax_slot(dy.device)
                 if split_mode() and cout % 32 == 0:
-                    gemm("nt", dy, weight_T(w2, ctx.weight_ref), dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
-                         amax_a=am_dy, amax_b=am_w, amax_c=am_dc)
+                    w2T = weight_T(w2, ctx.weight_ref)
+                    gemm("nt", dy, w2T, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
+                         amax_a=am_dy, amax_b=am_w, amax_c=am_dc, b_planes=weight_planes(w2T, ctx.weight_ref, "T2", am_w))
                 else:
                     am_dc = None
                     gemm("nn", dy, w2, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=ctot, ldc=ctot)
