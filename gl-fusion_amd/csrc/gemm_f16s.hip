@@ -28,6 +28,12 @@
 #ifndef GLF_GROUP_M_DEFAULT
 #define GLF_GROUP_M_DEFAULT 0
 #endif
+#ifndef GLF_PING_DEFAULT
+#define GLF_PING_DEFAULT false
+#endif
+#ifndef GLF_DEEP_DEFAULT
+#define GLF_DEEP_DEFAULT false
+#endif
 #ifndef GLF_SETPRIO_DEFAULT
 #define GLF_SETPRIO_DEFAULT 0
 #endif
@@ -104,7 +110,17 @@ constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 // BP: the B operand (weights) arrives PRE-SPLIT: two fp16 planes h, l (same element indexing as the fp32 operand, made
 // once per weight update by glf_split_f16_planes with the scale of args.amax_b); its staging is then two 8-byte loads and
 // two LDS stores per piece, no conversion (a third of the kernel's split arithmetic gone).
-template <bool GATHER, int NP, bool M16, bool BP>
+// DEEP: TWO raw register sets, so a tile's global loads are issued two iterations before they are converted (one with
+// the default pipeline) -- the kernel waits on its load path (SQ_WAIT_ANY 28 %; 48 KB in flight per CU against ~2.5 us of
+// loaded-fabric latency covers ~19 GB/s per CU, the kernel wants 28) -- paid for with the second fragment set: the k-step-1
+// fragments are read into the same registers in the middle of the iteration, behind two conversion pieces.
+// PING: the iteration is cut into a pure-MFMA segment (24 back-to-back MFMAs on fragments already in registers) and a staging
+// segment (convert + store the next tile, issue the loads of the one after, read the fragments of the tile to multiply next),
+// separated by barriers, and waves 4-7 run half an iteration behind waves 0-3: on every SIMD one wave is in its matrix
+// segment while its partner is in its vector / LDS segment (MI355X_MICROARCH.md, "Two waves per SIMD").  The default body
+// interleaves both kinds of work inside every wave, the two waves of a SIMD run it in lockstep, and the measured iteration
+// time is the SUM of both waves' MFMA and VALU time.
+template <bool GATHER, int NP, bool M16, bool BP, bool DEEP = false, bool PING = false>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -232,7 +248,15 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     const float* pa[4];
     const float* pb[2];
 
+    int tiles_left = ntiles;                  // DEEP pads the tile count to even: the tile after the last real one reads zeros
     auto advance = [&]() __attribute__((always_inline)) {
+        if (DEEP && tiles_left-- <= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pa[j] = p_zero + 4 * ac;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pb[j] = p_zero + 4 * ac;
+            return;
+        }
         if (++kc >= nkc) {
             kc = 0;
             tap = __ffs(rem_mask) - 1;
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) GLF_H8_LOAD_B(1) break;                            \
     }
 
-    if (!M16 && ntiles > 0) {
+    if (!M16 && !DEEP && !PING && ntiles > 0) {
         const int sw = (lane >> 2) & 3, hh = lane >> 5;
         const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
         const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
@@ -405,6 +429,161 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         GLF_H8_BODY(false, false, false)
     }
 
+
+    if (PING && !M16 && !DEEP) {
+        // (every wave of the workgroup executes the same number of barriers, also when it has no tiles at all)
+        const int sw = (lane >> 2) & 3, hh = lane >> 5;
+        const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
+        const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
+        // prologue: tile 0 -> buffer 0 (all waves), tile 1 raw in registers
+        if (ntiles > 0) {
+            advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, false, true) }
+            const bool more = ntiles > 1;
+            if (more) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, true, more) }
+        }
+        __syncthreads();
+        f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l, gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;
+#define GLF_P8_FRAGS(P, buf_, fo_)                                                                            \
+        {                                                                                                     \
+            const unsigned char* ab_ = smem_s + (buf_) * BUF8 + wm * 64 + (fo_);                              \
+            const unsigned char* bb_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + wn * 64 + (fo_);                  \
+            P##b0h = *reinterpret_cast<const f16x8*>(bb_);                                                    \
+            P##b1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                          \
+            P##a0h = *reinterpret_cast<const f16x8*>(ab_);                                                    \
+            P##a1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                          \
+            if (NP == 3) {                                                                                    \
+                P##a0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                        \
+                P##b0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                        \
+                P##b1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                              \
+                P##a1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                              \
+            } else { P##a0l = P##a0h; P##b0l = P##b0h; P##b1l = P##b1h; P##a1l = P##a1h; }                    \
+        }
+        int cur = 0, wr = 1, spare = 2;          // LDS buffers of tile i, tile i + 1, and the one tile i + 2 will go to
+        // iteration i: STAGE (tile i + 1 raw -> `wr`, loads of tile i + 2, fragments of tile i) | barrier | 24 MFMAs | barrier
+#define GLF_P8_BODY(CONV_, LOAD_)                                                                             \
+        {                                                                                                     \
+            if (LOAD_) advance();                                                                             \
+            GLF_H8_PIECE(0, wr, CONV_, LOAD_) GLF_H8_PIECE(1, wr, CONV_, LOAD_) GLF_H8_PIECE(2, wr, CONV_, LOAD_) \
+            GLF_H8_PIECE(3, wr, CONV_, LOAD_) GLF_H8_PIECE(4, wr, CONV_, LOAD_) GLF_H8_PIECE(5, wr, CONV_, LOAD_) \
+            GLF_P8_FRAGS(f, cur, fo0)                                                                         \
+            GLF_P8_FRAGS(g, cur, fo1)                                                                         \
+            __syncthreads();                                                                                  \
+            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_ROW3(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l)                                  \
+            GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
+            { const int t_ = cur; cur = wr; wr = spare; spare = t_; }                                         \
+            __syncthreads();                                                                                  \
+        }
+        if (wave >= 4) __syncthreads();          // waves 4-7 run half an iteration behind ...
+        int it = 0;
+        for (; it + 2 < ntiles; ++it) GLF_P8_BODY(true, true)
+        if (it + 1 < ntiles) { GLF_P8_BODY(true, false) ++it; }
+        if (it < ntiles) GLF_P8_BODY(false, false)
+        if (wave < 4) __syncthreads();           // ... and waves 0-3 wait for them at the end
+    }
+
+    if (DEEP && !M16 && ntiles > 0) {
+        const int sw = (lane >> 2) & 3, hh = lane >> 5;
+        const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
+        const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
+        float4 da[2][4], db[2][2];                       // two raw tiles: set S holds tile it + 2 (+ 1) at the top of iteration it
+#define GLF_D8_CONV_A(S, J, buf_)                                                                            \
+        {                                                                                                    \
+            const SplitH s = split4h(da[S][J], sc_a);                                                        \
+            unsigned char* d = smem_s + (buf_) * BUF8 + st_off + J * 64 * 64;                                \
+            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;     \
+        }
+#define GLF_D8_CONV_B(S, J, buf_)                                                                            \
+        {                                                                                                    \
+            const SplitH s = split4h(db[S][J], sc_b);                                                        \
+            unsigned char* d = smem_s + (buf_) * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64;                    \
+            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;     \
+        }
+#define GLF_D8_PIECE(pc, S, buf_, conv_, load_)                                                              \
+        switch (pc) {                                                                                        \
+            case 0: if (conv_) GLF_D8_CONV_A(S, 0, buf_) if (load_) da[S][0] = *reinterpret_cast<const float4*>(pa[0]); break; \
+            case 1: if (conv_) GLF_D8_CONV_A(S, 1, buf_) if (load_) da[S][1] = *reinterpret_cast<const float4*>(pa[1]); break; \
+            case 2: if (conv_) GLF_D8_CONV_A(S, 2, buf_) if (load_) da[S][2] = *reinterpret_cast<const float4*>(pa[2]); break; \
+            case 3: if (conv_) GLF_D8_CONV_A(S, 3, buf_) if (load_) da[S][3] = *reinterpret_cast<const float4*>(pa[3]); break; \
+            case 4: if (conv_) GLF_D8_CONV_B(S, 0, buf_) if (load_) db[S][0] = *reinterpret_cast<const float4*>(pb[0]); break; \
+            default: if (conv_) GLF_D8_CONV_B(S, 1, buf_) if (load_) db[S][1] = *reinterpret_cast<const float4*>(pb[1]); break; \
+        }
+        // The tile count is padded to even (ne): an odd count gets one all-zero tile at the end (advance() hands out the zero
+        // page), so that an iteration PAIR is the unit and the set index never depends on run-time parity.
+        // prologue: tiles 0, 1 -> the two sets; tile 0 -> buffer 0 (set 0 refilled with tile 2); tile 1 -> buffer 1 (set 1 <- tile 3)
+        const int ne = (ntiles + 1) & ~1;
+        advance();
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 0, 0, false, true) }
+        advance();
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 1, 0, false, true) }
+        {
+            const bool more = ne > 2;
+            if (more) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 0, 0, true, more) }
+            if (more) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 1, 1, true, more) }
+        }
+        __syncthreads();
+        f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l;
+#define GLF_D8_FRAGS(buf_, fo_)                                                                               \
+        {                                                                                                     \
+            const unsigned char* ab_ = smem_s + (buf_) * BUF8 + wm * 64 + (fo_);                              \
+            const unsigned char* bb_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + wn * 64 + (fo_);                  \
+            fb0h = *reinterpret_cast<const f16x8*>(bb_);                                                      \
+            fb1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                            \
+            fa0h = *reinterpret_cast<const f16x8*>(ab_);                                                      \
+            fa1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                            \
+            if (NP == 3) {                                                                                    \
+                fa0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                          \
+                fb0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                          \
+                fb1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                                \
+                fa1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                                \
+            } else { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }                                    \
+        }
+        GLF_D8_FRAGS(0, fo0)
+        int cur = 0, nxt = 1, wr = 2;
+        // iteration `it` (set S = it & 1): multiplies tile it, converts tile it + 2 out of set S into `wr`, refills set S with
+        // tile it + 4
+#define GLF_D8_BODY(S, CONV_, LOAD_, NEXT_)                                                                   \
+        {                                                                                                     \
+            if (LOAD_) advance();                                                                             \
+            GLF_D8_PIECE(0, S, wr, CONV_, LOAD_)                                                              \
+            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_D8_PIECE(1, S, wr, CONV_, LOAD_)                                                              \
+            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_D8_FRAGS(cur, fo1)              /* k-step 1 of this tile into the same registers ... */         \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_D8_PIECE(2, S, wr, CONV_, LOAD_)  /* ... whose LDS latency these two pieces cover */            \
+            GLF_D8_PIECE(3, S, wr, CONV_, LOAD_)                                                              \
+            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_D8_PIECE(4, S, wr, CONV_, LOAD_)                                                              \
+            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if (NEXT_) GLF_D8_FRAGS(nxt, fo0)   /* k-step 0 of the next tile (converted one iteration ago) */   \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_D8_PIECE(5, S, wr, CONV_, LOAD_)                                                              \
+            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            __syncthreads();                                                                                  \
+        }
+        // steady state while tiles it + 4, it + 5 exist; then two pairs: [convert, convert] (if four tiles are left) and
+        // [fragments only, last] -- compile-time flags throughout (run-time flags or a switch over the remaining count made
+        // hipcc spill hundreds of registers)
+        int it = 0;
+        for (; it + 4 < ne; it += 2) { GLF_D8_BODY(0, true, true, true) GLF_D8_BODY(1, true, true, true) }
+        if (ne - it == 4) { GLF_D8_BODY(0, true, false, true) GLF_D8_BODY(1, true, false, true) }
+        GLF_D8_BODY(0, false, false, true)
+        GLF_D8_BODY(1, false, false, false)
+    }
 
     // ---- 16x16x32 variant: accumulators t[i][j] (main) / u[i][j] (mixed), i = 16-row slab, j = 16-column slab of the
     //      wave's 64 x 64 tile ----
@@ -1061,6 +1240,10 @@ int init_gemm_f16s_attrs() {
     SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true, false>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<false, 1, true, false>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<true, 1, true, false>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false, true>), SMEM_ROWS_H8)
@@ -1117,7 +1300,15 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     a.flags = prio | ((group_m & 0xff) << 8);
 #define GLF_LAUNCH_ROWS(G, NP_, M_, BP_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, M_, BP_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
     const bool bp = a.Bh != nullptr && a.Bl != nullptr;          // pre-split B planes (32x32x16 kernels only)
-    if (nprod == 3) {
+    static const bool deep = [] { const char* e = getenv("GLF_DEEP"); return e ? e[0] != '0' : GLF_DEEP_DEFAULT; }();
+    static const bool ping = [] { const char* e = getenv("GLF_PING"); return e ? e[0] != '0' : GLF_PING_DEFAULT; }();
+    if (nprod == 3 && ping && !bp && !m16) {
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    } else if (nprod == 3 && deep && !bp && !m16) {
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+    } else if (nprod == 3) {
         if (bp) { if (gather) GLF_LAUNCH_ROWS(true, 3, false, true); else GLF_LAUNCH_ROWS(false, 3, false, true); }
         else if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 3, true, false); else GLF_LAUNCH_ROWS(false, 3, true, false); }
         else { if (gather) GLF_LAUNCH_ROWS(true, 3, false, false); else GLF_LAUNCH_ROWS(false, 3, false, false); }
