@@ -33,7 +33,7 @@ class GemmParams(C.Structure):
         ("amax_a", C.c_void_p), ("amax_b", C.c_void_p), ("amax_c", C.c_void_p),
         ("colstats", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("b_planes_h", C.c_void_p), ("b_planes_l", C.c_void_p),
+        ("a_presplit", C.c_int32), ("b_presplit", C.c_int32),
         ("precision", C.c_int32),
     ]
 

@@ -23,7 +23,7 @@ struct GemmArgs {
     float* amax_c;                              // f16x3 only: receives max(*amax_c, max|C written|) (null = not wanted)
     double* colstats;                           // f16x3 NT only: [2][N] += column sums of C and of C^2 (null = not wanted)
     float* partial;                             // TN only: partial-sum slabs [batch*split][kept taps][M][N] (null = atomics into C)
-    const void* Bh; const void* Bl;             // f16x3 / f16 NT kernel: B pre-split into fp16 planes (null = split in the kernel)
+    int a_presplit, b_presplit;                 // f16x3 / f16 kernels: the operand pointer is the packed pre-split image (glf_split_f16_packed)
     int flags;                                  // f16x3 rows kernel: bit 0 = waves 4-7 run at s_setprio 1 (the younger half of an 8-wave workgroup)
 };
 constexpr int ZERO_PAGE_FLOATS = 1 << 18;
@@ -39,7 +39,7 @@ int init_gemm_f16s_attrs();                    // gemm_f16s.hip
 int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);   // nprod: 3 = f16x3, 1 = f16
 int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);
 int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s);
-int launch_split_planes(const float* x, long long n, const float* amax, void* h, void* l, hipStream_t s);   // gemm_f16s.hip
+int launch_split_packed(const float* x, long long rows, int cols, long long ld, const float* amax, float* out, long long ldo, hipStream_t s);   // gemm_f16s.hip
 float* amax_scratch(int n, hipStream_t s);     // n consecutive device floats from the ring of stream s (glf_api.hip)
 const float* zero_page();                      // ZERO_PAGE_FLOATS zeros on the device (glf_api.hip)
 bool f16s_rows_ok(const GemmArgs& a);
@@ -182,7 +182,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
-    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr; a.flags = 0; a.Bh = p->b_planes_h; a.Bl = p->b_planes_l;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr; a.flags = 0; a.a_presplit = p->a_presplit; a.b_presplit = p->b_presplit;
     return a;
 }
 

@@ -64,6 +64,14 @@ __device__ __forceinline__ SplitH split4h(const float4 v, const float s) {
     return o;
 }
 
+// a float4 of the packed pre-split image {h0 h1 h2 h3 | l0 l1 l2 l3} -> the two pieces (a bit-cast)
+__device__ __forceinline__ SplitH unpack4h(const float4 v) {
+    SplitH o;
+    o.h = __builtin_bit_cast(f16x4, make_float2(v.x, v.y));
+    o.l = __builtin_bit_cast(f16x4, make_float2(v.z, v.w));
+    return o;
+}
+
 // power-of-two operand scale from its max magnitude: amax*s in [2^13, 2^14); inv = 1/s.  No pointer, zero,
 // denormal-range or non-finite amax: s = 1.
 __device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& inv) {
@@ -100,16 +108,22 @@ constexpr int BM8 = 256;
 constexpr int NT8 = 512;
 constexpr int PL_A8 = BM8 * 64, PL_B8 = BN * 64;
 constexpr int BUF8 = 2 * PL_A8 + 2 * PL_B8;
+#ifdef GLF_STAMPS       // diagnostic build (profiles/ubench/stamps.sh): per-wave s_memtime stamps of 16 main-loop iterations of one workgroup
+constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16 + 8192;
+#else
 constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
+#endif
 
 // M16: the products run on v_mfma_f32_16x16x32_f16 (16 x 16 output tiles, the whole 32-deep K-tile per instruction)
 // instead of v_mfma_f32_32x32x16_f16: the same MFMA cycles per FLOP, the same LDS fragment traffic, but under load the
 // chip holds a higher clock on the smaller shape (MI355X_MICROARCH.md, DVFS item 7).  LDS rows keep their 64-byte
 // layout; only the 16-byte chunk swizzle differs (chunk g(c) ^ (row >> 2 & 3), g = 0,3,1,2: conflict-free ds_read_b128 for
 // the lane -> (row = lane & 15, chunk = lane >> 4) fragment map).
-// BP: the B operand (weights) arrives PRE-SPLIT: two fp16 planes h, l (same element indexing as the fp32 operand, made
-// once per weight update by glf_split_f16_planes with the scale of args.amax_b); its staging is then two 8-byte loads and
-// two LDS stores per piece, no conversion (a third of the kernel's split arithmetic gone).
+// PA / BP: the A / B operand arrives PRE-SPLIT in the packed image glf_split_f16_packed writes: every aligned group of four
+// consecutive elements (16 bytes of fp32) is replaced IN PLACE by {h0 h1 h2 h3 l0 l1 l2 l3} (fp16), x * s = h + 2^-11 l with the
+// scale of args.amax_a / amax_b.  Same byte size, same strides, same addressing as the fp32 operand -- the staging path keeps its
+// loads, pointers, zero page and gather logic and only drops the conversion (a bit-cast instead of ~18 VALU per float4): the
+// operand is split ONCE (by glf_split_f16_packed, per tensor) instead of in every tile of every launch that reads it.
 // DEEP: TWO raw register sets, so a tile's global loads are issued two iterations before they are converted (one with
 // the default pipeline) -- the kernel waits on its load path (SQ_WAIT_ANY 28 %; 48 KB in flight per CU against ~2.5 us of
 // loaded-fabric latency covers ~19 GB/s per CU, the kernel wants 28) -- paid for with the second fragment set: the k-step-1
@@ -120,7 +134,7 @@ constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 // segment while its partner is in its vector / LDS segment (MI355X_MICROARCH.md, "Two waves per SIMD").  The default body
 // interleaves both kinds of work inside every wave, the two waves of a SIMD run it in lockstep, and the measured iteration
 // time is the SUM of both waves' MFMA and VALU time.
-template <bool GATHER, int NP, bool M16, bool BP, bool DEEP = false, bool PING = false>
+template <bool GATHER, int NP, bool M16, bool BP, bool DEEP = false, bool PING = false, bool PA = false>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -140,6 +154,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     unsigned* s_mask = reinterpret_cast<unsigned*>(smem_s + 3 * BUF8);
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2     // workgroup-level stamps only: entry, main loop start / end, exit (no per-iteration cost)
+    unsigned long long wg_t0 = __builtin_amdgcn_s_memtime(), wg_t1 = 0, wg_t2 = 0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -195,9 +212,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     }
     const int bz = blockIdx.z;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
-    // BP: B addresses the h plane in units of floats (= 2 halves); the l plane sits b_delta floats further
-    const float* __restrict__ B = BP ? reinterpret_cast<const float*>(args.Bh) + (((long long)bz * p_bsb) >> 1) : p_B + (long long)bz * p_bsb;
-    const long long b_delta = BP ? (reinterpret_cast<const float*>(args.Bl) - reinterpret_cast<const float*>(args.Bh)) : 0;
+    const float* __restrict__ B = p_B + (long long)bz * p_bsb;
     float* __restrict__ C = p_C + (long long)bz * p_bsc;
 
     const int ac = tid & 7, ar = tid >> 3;              // 8 float4 per 32-deep row; rows ar + 64 j
@@ -272,26 +287,17 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                 }
                 pa[j] = (off >= 0 ? A + off : p_zero) + 4 * ac;          // padding / overhang rows read the zero page
             }
-            if (BP) {
-                const float* Bt = B + (((long long)tap * p_tsb) >> 1);
+            const float* Bt = B + (long long)tap * p_tsb;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = min(tn * BN + ar + 64 * j, pN - 1);      // overhang rows repeat the last one: their columns are never stored
-                    pb[j] = Bt + (((long long)n * p_ldb) >> 1) + 2 * ac;
-                }
-            } else {
-                const float* Bt = B + (long long)tap * p_tsb;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = tn * BN + ar + 64 * j;
-                    pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + 4 * ac;
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int n = tn * BN + ar + 64 * j;
+                pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + 4 * ac;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pa[j] += BK;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pb[j] += BP ? BK / 2 : BK;
+            for (int j = 0; j < 2; ++j) pb[j] += BK;
         }
     };
     // swizzled staging offset of this thread inside a 64-byte row: 16-byte chunk (ac>>1) ^ ((row>>2)&3), half ac&1
@@ -299,9 +305,14 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     const int st_off = ar * 64 + (((st_chunk ^ ((ar >> 2) & 3)) << 4) | ((ac & 1) << 3));
 #define GLF_H8_CONV_A(J, buf_)                                                                               \
     {                                                                                                        \
-        const SplitH s = split4h(ra[J], sc_a);                                                               \
         unsigned char* d = smem_s + (buf_) * BUF8 + st_off + J * 64 * 64;                                    \
-        *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;         \
+        if (PA) {                                                                                            \
+            *reinterpret_cast<float2*>(d) = make_float2(ra[J].x, ra[J].y);                                   \
+            if (NP == 3) *reinterpret_cast<float2*>(d + PL_A8) = make_float2(ra[J].z, ra[J].w);              \
+        } else {                                                                                             \
+            const SplitH s = split4h(ra[J], sc_a);                                                           \
+            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;     \
+        }                                                                                                    \
     }
 #define GLF_H8_CONV_B(J, buf_)                                                                               \
     {                                                                                                        \
@@ -314,26 +325,22 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;     \
         }                                                                                                    \
     }
-#define GLF_H8_LOAD_B(J)                                                                                     \
-    {                                                                                                        \
-        if (BP) {                                                                                            \
-            const float2 h_ = *reinterpret_cast<const float2*>(pb[J]);                                       \
-            float2 l_ = h_;                                                                                  \
-            if (NP == 3) l_ = *reinterpret_cast<const float2*>(pb[J] + b_delta);                             \
-            rb[J] = make_float4(h_.x, h_.y, l_.x, l_.y);                                                     \
-        } else {                                                                                             \
-            rb[J] = *reinterpret_cast<const float4*>(pb[J]);                                                 \
-        }                                                                                                    \
-    }
+#define GLF_H8_LOAD_B(J) rb[J] = *reinterpret_cast<const float4*>(pb[J]);
     // piece pc (0..5): convert + store registers of tile t+1, then refill them with tile t+2
+// A pre-split operand goes from its load registers straight into LDS: the store must stay AHEAD of the load that refills the
+// same registers (GLF_H8_PIN).  Left to itself the scheduler hoists the load above the store, the two values then need two
+// register sets, and the copy it adds at the loop's back edge waits for loads issued a few hundred cycles earlier --
+// s_waitcnt vmcnt(1) in every iteration, the whole global-load latency exposed (measured: the pre-split kernel 4 % faster
+// than the splitting one instead of the ~1.4x its instruction count promises).
+#define GLF_H8_PIN(P_) if (P_) __builtin_amdgcn_sched_barrier(0);
 #define GLF_H8_PIECE(pc, buf_, conv_, load_)                                                                 \
     switch (pc) {                                                                                            \
-        case 0: if (conv_) GLF_H8_CONV_A(0, buf_) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0]); break; \
-        case 1: if (conv_) GLF_H8_CONV_A(1, buf_) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); break; \
-        case 2: if (conv_) GLF_H8_CONV_A(2, buf_) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); break; \
-        case 3: if (conv_) GLF_H8_CONV_A(3, buf_) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); break; \
-        case 4: if (conv_) GLF_H8_CONV_B(0, buf_) if (load_) GLF_H8_LOAD_B(0) break;                             \
-        default: if (conv_) GLF_H8_CONV_B(1, buf_) if (load_) GLF_H8_LOAD_B(1) break;                            \
+        case 0: if (conv_) GLF_H8_CONV_A(0, buf_) GLF_H8_PIN(PA) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0]); GLF_H8_PIN(PA) break; \
+        case 1: if (conv_) GLF_H8_CONV_A(1, buf_) GLF_H8_PIN(PA) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); GLF_H8_PIN(PA) break; \
+        case 2: if (conv_) GLF_H8_CONV_A(2, buf_) GLF_H8_PIN(PA) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); GLF_H8_PIN(PA) break; \
+        case 3: if (conv_) GLF_H8_CONV_A(3, buf_) GLF_H8_PIN(PA) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); GLF_H8_PIN(PA) break; \
+        case 4: if (conv_) GLF_H8_CONV_B(0, buf_) GLF_H8_PIN(BP) if (load_) GLF_H8_LOAD_B(0) GLF_H8_PIN(BP) break;      \
+        default: if (conv_) GLF_H8_CONV_B(1, buf_) GLF_H8_PIN(BP) if (load_) GLF_H8_LOAD_B(1) GLF_H8_PIN(BP) break;     \
     }
 
     if (!M16 && !DEEP && !PING && ntiles > 0) {
@@ -398,35 +405,129 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 #else
 #define GLF_SGB_HALF()
 #endif
+#if defined(GLF_STAMPS) && GLF_STAMPS == 1
+        unsigned long long st_[5] = {0, 0, 0, 0, 0};
+        const bool stamp_on = args.partial != nullptr && blockIdx.x == gridDim.x / 2;
+        unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(smem_s + 3 * BUF8 + 16);
+#define GLF_STAMP(k_) { __builtin_amdgcn_sched_barrier(0); st_[k_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define GLF_STAMP_FLUSH()                                                                                     \
+            if (stamp_on && it >= 16 && it < 32 && lane == 0) {                                               \
+                unsigned long long* d_ = stamp_lds + (wave * 16 + (it - 16)) * 8;                             \
+                d_[0] = st_[0]; d_[1] = st_[1]; d_[2] = st_[2]; d_[3] = st_[3]; d_[4] = st_[4];               \
+            }
+#else
+#define GLF_STAMP(k_)
+#define GLF_STAMP_FLUSH()
+#endif
 #define GLF_H8_BODY(CONV_, LOAD_, NEXT_)                                                                      \
         {                                                                                                     \
+            GLF_STAMP(0)                                                                                      \
             if (LOAD_) advance();                                                                             \
             f16x8 gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;                                             \
             GLF_H8_FRAGS(g, cur, fo1)                                                                         \
             __builtin_amdgcn_sched_barrier(0);    /* keep the fragment reads up here (hipcc sinks them to their use) */ \
             GLF_H8_PIECE(0, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
+            GLF_STAMP(1)                                                                                      \
             GLF_H8_PIECE(1, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
             GLF_H8_PIECE(2, wr, CONV_, LOAD_)                                                                 \
             GLF_SGB_HALF()                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                \
+            GLF_STAMP(2)                                                                                      \
             if (NEXT_) GLF_H8_FRAGS(f, nxt, fo0)                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             GLF_H8_PIECE(3, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l)                                  \
+            GLF_STAMP(3)                                                                                      \
             GLF_H8_PIECE(4, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
             GLF_H8_PIECE(5, wr, CONV_, LOAD_)                                                                 \
             GLF_SGB_HALF()                                                                                    \
             { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            GLF_STAMP(4)                                                                                      \
             __syncthreads();                                                                                  \
+            GLF_STAMP_FLUSH()                                                                                 \
+        }
+// Both operands pre-split: the iteration has no conversion arithmetic left, only 24 MFMAs, 16 fragment reads, 6 LDS stores
+// and 6 global loads per wave.  They are placed one by one (GLF_IL_*: a slot = the memory operations issued behind one MFMA,
+// pinned by sched_barriers): a wave issues in order, so whatever sits between two of ITS MFMAs delays the second one unless it
+// fits the ~24 issue cycles the first leaves free.  Slots 1-4: the k-step-1 fragments (two reads each); 5: pointer advance;
+// 6-11: one staging piece each (store the registers loaded an iteration ago, refill them); 12-15: the next tile's k-step-0
+// fragments into registers whose last reader has issued; MFMAs 16-24 run with nothing behind them, so every LDS operation
+// has landed when the barrier is reached.
+#define GLF_IL_RD(P, w_, base_, off_) P##w_ = *reinterpret_cast<const f16x8*>((base_) + (off_));
+#define GLF_IL_PIN() __builtin_amdgcn_sched_barrier(0);
+#define GLF_IL_MM(c_, a_, b_) c_ = GLF_MFMA_F16(a_, b_, c_);
+#define GLF_IL_ROW(c0, c1, m0, m1, ah, al, b0h, b0l, b1h, b1l, S1_, S2_, S3_, S4_, S5_, S6_)                   \
+            GLF_IL_MM(c0, ah, b0h) GLF_IL_PIN() S1_ GLF_IL_PIN()                                              \
+            GLF_IL_MM(c1, ah, b1h) GLF_IL_PIN() S2_ GLF_IL_PIN()                                              \
+            if (NP == 3) { GLF_IL_MM(m0, al, b0h) GLF_IL_PIN() } S3_ GLF_IL_PIN()                             \
+            if (NP == 3) { GLF_IL_MM(m1, al, b1h) GLF_IL_PIN() } S4_ GLF_IL_PIN()                             \
+            if (NP == 3) { GLF_IL_MM(m0, ah, b0l) GLF_IL_PIN() } S5_ GLF_IL_PIN()                             \
+            if (NP == 3) { GLF_IL_MM(m1, ah, b1l) GLF_IL_PIN() } S6_ GLF_IL_PIN()
+#define GLF_H8_BODY_IL(CONV_, LOAD_, NEXT_)                                                                   \
+        {                                                                                                     \
+            GLF_STAMP(0)                                                                                      \
+            f16x8 gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;                                             \
+            const unsigned char* ga_ = smem_s + cur * BUF8 + wm * 64 + fo1;                                   \
+            const unsigned char* gb_ = smem_s + cur * BUF8 + 2 * PL_A8 + wn * 64 + fo1;                       \
+            const unsigned char* na_ = smem_s + nxt * BUF8 + wm * 64 + fo0;                                   \
+            const unsigned char* nb_ = smem_s + nxt * BUF8 + 2 * PL_A8 + wn * 64 + fo0;                       \
+            GLF_IL_ROW(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l,                                \
+                { GLF_IL_RD(g, b0h, gb_, 0) GLF_IL_RD(g, a0h, ga_, 0) },                                      \
+                { GLF_IL_RD(g, b1h, gb_, 32 * 64) if (NP == 3) { GLF_IL_RD(g, a0l, ga_, PL_A8) } },           \
+                { if (NP == 3) { GLF_IL_RD(g, b0l, gb_, PL_B8) GLF_IL_RD(g, b1l, gb_, 32 * 64 + PL_B8) } },   \
+                { GLF_IL_RD(g, a1h, ga_, 32 * 64) if (NP == 3) { GLF_IL_RD(g, a1l, ga_, 32 * 64 + PL_A8) } }, \
+                { if (LOAD_) advance(); },                                                                    \
+                { GLF_H8_PIECE(0, wr, CONV_, LOAD_) })                                                        \
+            GLF_STAMP(1)                                                                                      \
+            GLF_IL_ROW(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l,                                \
+                { GLF_H8_PIECE(1, wr, CONV_, LOAD_) },                                                        \
+                { GLF_H8_PIECE(2, wr, CONV_, LOAD_) },                                                        \
+                { GLF_H8_PIECE(3, wr, CONV_, LOAD_) },                                                        \
+                { GLF_H8_PIECE(4, wr, CONV_, LOAD_) },                                                        \
+                { GLF_H8_PIECE(5, wr, CONV_, LOAD_) },                                                        \
+                { if (NEXT_) { GLF_IL_RD(f, a0h, na_, 0) if (NP == 3) { GLF_IL_RD(f, a0l, na_, PL_A8) } } })  \
+            if (NP != 3) { ga0l = ga0h; gb0l = gb0h; gb1l = gb1h; ga1l = ga1h; }                              \
+            GLF_STAMP(2)                                                                                      \
+            GLF_IL_ROW(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l,                                \
+                { if (NEXT_) { GLF_IL_RD(f, b0h, nb_, 0) GLF_IL_RD(f, b1h, nb_, 32 * 64) } },                 \
+                { if (NEXT_ && NP == 3) { GLF_IL_RD(f, b0l, nb_, PL_B8) GLF_IL_RD(f, b1l, nb_, 32 * 64 + PL_B8) } }, \
+                { if (NEXT_) { GLF_IL_RD(f, a1h, na_, 32 * 64) if (NP == 3) { GLF_IL_RD(f, a1l, na_, 32 * 64 + PL_A8) } } }, \
+                {}, {}, {})                                                                                   \
+            GLF_STAMP(3)                                                                                      \
+            GLF_IL_ROW(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l, {}, {}, {}, {}, {}, {})        \
+            if (NP != 3 && NEXT_) { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }                     \
+            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            GLF_STAMP(4)                                                                                      \
+            __syncthreads();                                                                                  \
+            GLF_STAMP_FLUSH()                                                                                 \
         }
         int it = 0;
-        for (; it + 3 < ntiles; ++it) GLF_H8_BODY(true, true, true)
-        if (it + 2 < ntiles) { GLF_H8_BODY(true, false, true) ++it; }
-        if (it + 1 < ntiles) { GLF_H8_BODY(false, false, true) ++it; }
-        GLF_H8_BODY(false, false, false)
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+        wg_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (PA && BP) {
+            for (; it + 3 < ntiles; ++it) GLF_H8_BODY_IL(true, true, true)
+            if (it + 2 < ntiles) { GLF_H8_BODY_IL(true, false, true) ++it; }
+            if (it + 1 < ntiles) { GLF_H8_BODY_IL(false, false, true) ++it; }
+            GLF_H8_BODY_IL(false, false, false)
+        } else {
+            for (; it + 3 < ntiles; ++it) GLF_H8_BODY(true, true, true)
+            if (it + 2 < ntiles) { GLF_H8_BODY(true, false, true) ++it; }
+            if (it + 1 < ntiles) { GLF_H8_BODY(false, false, true) ++it; }
+            GLF_H8_BODY(false, false, false)
+        }
+#if defined(GLF_STAMPS) && GLF_STAMPS == 1
+        if (stamp_on) {
+            __syncthreads();
+            for (int i = tid; i < 8 * 16 * 8; i += NT8) reinterpret_cast<unsigned long long*>(args.partial)[i] = stamp_lds[i];
+        }
+#endif
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+        wg_t2 = __builtin_amdgcn_s_memtime();
+#endif
     }
 
 
@@ -693,7 +794,72 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     };
     // column statistics in double from the first product on: E[x^2] - E[x]^2 cancels badly when a channel's values are close
     // together (the ASPP pooled branch: N nearly equal frame averages), fp32 partial sums cost 4e-4 on its BatchNorm output
-    if (!M16) {
+    // Fast epilogue (everything but the atomics of per-tap rectangles and unaligned outputs): every wave parks its 64 x 64
+    // results in LDS (free once the main loop's last barrier is passed: 8 x 16 KB) and stores them as whole 16-byte pieces
+    // of rows -- 16 global_store_dwordx4 per lane instead of 64 one-dword stores.  The one-dword form took ~19 k cycles per
+    // workgroup (in-kernel stamps, profiles/r02_stamps_*.txt): 13 % of a K = 2048 tile's time, 40 % of a K = 512 tile's,
+    // with the matrix pipe idle (one workgroup per CU: nothing else runs meanwhile).
+    const bool wide_store = !M16 && p_rect != 1 && (p_ldc % 4) == 0 && (pN % 4) == 0 && (reinterpret_cast<size_t>(C) % 16) == 0 &&
+                            (p_bsc % 4) == 0;
+    if (wide_store) {
+        float* tile = reinterpret_cast<float*>(smem_s) + wave * (64 * 64);
+        {
+            const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+            auto park = [&](const f32x16& acc, int ti, int tj) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tile[(32 * ti + (r & 3) + 8 * (r >> 2) + row_l) * 64 + 32 * tj + col_l] = acc[r];
+            };
+            park(c00 + m00 * 0x1p-11f, 0, 0); park(c01 + m01 * 0x1p-11f, 0, 1);
+            park(c10 + m10 * 0x1p-11f, 1, 0); park(c11 + m11 * 0x1p-11f, 1, 1);
+        }
+        __syncthreads();
+        const int c4 = 4 * (lane & 15), r0 = lane >> 4;
+        const int col = tn * BN + wn + c4;
+        double cs[4] = {0.0, 0.0, 0.0, 0.0}, cq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (col < pN) {
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = p_bias[col + j];
+            }
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int rin = r0 + 4 * i;
+                const int row = tm * BM8 + wm + rin;
+                if (row >= pMe) continue;
+                long long orow = row;
+                if (p_rect) {
+                    const int hw = r_h * r_w;
+                    const int n = row / hw, rem = row - n * hw;
+                    const int yy = rem / r_w;
+                    orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+                }
+                const float4 a = *reinterpret_cast<const float4*>(tile + rin * 64 + c4);
+                float* dst = C + orow * p_ldc + col;
+                float v[4] = {p_alpha * a.x + bv[0], p_alpha * a.y + bv[1], p_alpha * a.z + bv[2], p_alpha * a.w + bv[3]};
+                if (p_accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(dst);
+                    v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (p_colstats) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const double vd = (double)v[j]; cs[j] += vd; cq[j] = fma(vd, vd, cq[j]); }
+                }
+            }
+        }
+        if (p_colstats) {
+            // lanes l, l + 16, l + 32, l + 48 hold the four row groups of the same four columns
+            double* st = args.colstats;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cs[j] += __shfl_xor(cs[j], 16, 64); cq[j] += __shfl_xor(cq[j], 16, 64);
+                cs[j] += __shfl_xor(cs[j], 32, 64); cq[j] += __shfl_xor(cq[j], 32, 64);
+                if (lane < 16 && col + j < pN) { atomicAdd(st + col + j, cs[j]); atomicAdd(st + pN + col + j, cq[j]); }
+            }
+        }
+    } else if (!M16) {
         const int col_l = lane & 31, row_l = 4 * (lane >> 5);
         auto emit = [&](const f32x16& acc, int ti, int tj, double& cs, double& cq) {
             const int col = tn * BN + wn + 32 * tj + col_l;
@@ -748,6 +914,16 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
     }
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+    if (args.partial != nullptr && blockIdx.x == gridDim.x / 2) {
+        __builtin_amdgcn_s_waitcnt(0);          // the stores of this wave's part of C have been accepted
+        const unsigned long long wg_t3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* d_ = reinterpret_cast<unsigned long long*>(args.partial) + wave * 4;
+            d_[0] = wg_t0; d_[1] = wg_t1; d_[2] = wg_t2; d_[3] = wg_t3;
+        }
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -759,7 +935,7 @@ constexpr int PLANE_T = 32 * RST;
 constexpr int OPER_T = 2 * PLANE_T;
 constexpr size_t SMEM_TN_H = 2 * OPER_T + 32 * sizeof(int);
 
-template <bool GATHER, int NP>
+template <bool GATHER, int NP, bool PA = false, bool PB = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_accumulate = args.accumulate, p_split = args.split;
@@ -852,8 +1028,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     };
 #define GLF_HT_STORE(J)                                                                                    \
     {                                                                                                      \
-        const SplitH sa = split4h(ra[J], sc_a);                                                            \
-        const SplitH sb = split4h(rb[J], sc_b);                                                            \
+        const SplitH sa = PA ? unpack4h(ra[J]) : split4h(ra[J], sc_a);                                     \
+        const SplitH sb = PB ? unpack4h(rb[J]) : split4h(rb[J], sc_b);                                     \
         unsigned char* da = As + (rr + 8 * J) * RST + c4 * 8;                                              \
         unsigned char* db = Bs + (rr + 8 * J) * RST + c4 * 8;                                              \
         *reinterpret_cast<f16x4*>(da) = sa.h; if (NP == 3) *reinterpret_cast<f16x4*>(da + PLANE_T) = sa.l; \
@@ -942,7 +1118,7 @@ constexpr int PA8 = 32 * RSA, PB8 = 32 * RSB;
 constexpr int TBUF8 = 2 * PA8 + 2 * PB8;
 constexpr size_t SMEM_TN_H8 = 2 * TBUF8;
 
-template <bool GATHER, int NP>
+template <bool GATHER, int NP, bool PA = false, bool PB = false>
 __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_accumulate = args.accumulate, p_split = args.split;
@@ -1072,13 +1248,13 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     const int st_a = ra0 * RSA + ca * 8, st_b = rb0 * RSB + cb * 8;
 #define GLF_T8_CONV_A(J, buf_)                                                                               \
     {                                                                                                        \
-        const SplitH s = split4h(ra[J], sc_a);                                                               \
+        const SplitH s = PA ? unpack4h(ra[J]) : split4h(ra[J], sc_a);                                        \
         unsigned char* d = smem_s + (buf_) * TBUF8 + st_a + J * 8 * RSA;                                     \
         *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PA8) = s.l;           \
     }
 #define GLF_T8_CONV_B(J, buf_)                                                                               \
     {                                                                                                        \
-        const SplitH s = split4h(rb[J], sc_b);                                                               \
+        const SplitH s = PB ? unpack4h(rb[J]) : split4h(rb[J], sc_b);                                        \
         unsigned char* d = smem_s + (buf_) * TBUF8 + 2 * PA8 + st_b + J * 16 * RSB;                          \
         *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PB8) = s.l;           \
     }
@@ -1203,16 +1379,20 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     }
 }
 
-// x -> the two fp16 planes of x * s, s = the power of two pow2_scale() derives from *amax (what the kernels do in their
-// staging path, done once for an operand that is reused: weights)
-__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ x, long long n4, const float* __restrict__ amax,
-                                                           f16x4* __restrict__ h, f16x4* __restrict__ l) {
+// x [rows][cols] (row stride ld, cols % 4 == 0) -> the packed pre-split image out (row stride ldo): every float4 of x
+// becomes {h0 h1 h2 h3 l0 l1 l2 l3}, x * s = h + 2^-11 l, s = the power of two pow2_scale() derives from *amax -- exactly
+// what the contraction kernels compute in their staging path
+__global__ __launch_bounds__(256) void split_packed_kernel(const float* __restrict__ x, long long rows, int cols4, long long ld,
+                                                           const float* __restrict__ amax, float* __restrict__ out, long long ldo) {
     float sc, inv;
     pow2_scale(amax, sc, inv);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const SplitH s = split4h(x[i], sc);
-        h[i] = s.h;
-        l[i] = s.l;
+    const long long total = rows * cols4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols4;
+        const int c = (int)(i - r * cols4) * 4;
+        const SplitH s = split4h(*reinterpret_cast<const float4*>(x + r * ld + c), sc);
+        const float2 h = __builtin_bit_cast(float2, s.h), l = __builtin_bit_cast(float2, s.l);
+        *reinterpret_cast<float4*>(out + r * ldo + c) = make_float4(h.x, h.y, l.x, l.y);
     }
 }
 
@@ -1220,13 +1400,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restr
 
 namespace glf {
 
-int launch_split_planes(const float* x, long long n, const float* amax, void* h, void* l, hipStream_t s) {
-    const long long n4 = n / 4;
-    long long blocks = (n4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n4, amax,
-                       reinterpret_cast<f16x4*>(h), reinterpret_cast<f16x4*>(l));
-    return check_launch("split_f16_planes");
+int launch_split_packed(const float* x, long long rows, int cols, long long ld, const float* amax, float* out, long long ldo, hipStream_t s) {
+    const long long total = rows * (cols / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, rows, cols / 4, ld, amax, out, ldo);
+    return check_launch("split_f16_packed");
 }
 
 int init_gemm_f16s_attrs() {
@@ -1234,30 +1413,22 @@ int init_gemm_f16s_attrs() {
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false>), SMEM_ROWS_H8)
+#define SET_ROWS(G, NP_, PA_, PB_) SET_ATTR((gemm_rows_f16s8_kernel<G, NP_, false, PB_, false, false, PA_>), SMEM_ROWS_H8)
+#define SET_TN(G, NP_, PA_, PB_) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), SMEM_TN_H) SET_ATTR((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), SMEM_TN_H8)
+#define SET_ALL(G, NP_) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
+                        SET_TN(G, NP_, false, false) SET_TN(G, NP_, true, false) SET_TN(G, NP_, false, true) SET_TN(G, NP_, true, true)
+    SET_ALL(false, 3) SET_ALL(true, 3) SET_ALL(false, 1) SET_ALL(true, 1)
+#ifdef GLF_EXPERIMENTS      // the measured-and-dropped variants of DESIGN.md section 8 (16x16x32 MFMA, deep prefetch, ping-pong)
     SET_ATTR((gemm_rows_f16s8_kernel<false, 3, true, false>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, true, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, true, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, true>), SMEM_ROWS_H8)
     SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_tn_f16s_kernel<false, 3>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s_kernel<true, 3>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s8_kernel<false, 3>), SMEM_TN_H8)
-    SET_ATTR((gemm_tn_f16s8_kernel<true, 3>), SMEM_TN_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 1, false, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 1, false, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_tn_f16s_kernel<false, 1>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s_kernel<true, 1>), SMEM_TN_H)
-    SET_ATTR((gemm_tn_f16s8_kernel<false, 1>), SMEM_TN_H8)
-    SET_ATTR((gemm_tn_f16s8_kernel<true, 1>), SMEM_TN_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), SMEM_ROWS_H8)
+    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), SMEM_ROWS_H8)
+#endif
+#undef SET_ALL
+#undef SET_TN
+#undef SET_ROWS
 #undef SET_ATTR
     return GLF_OK;
 }
@@ -1270,6 +1441,17 @@ bool f16s_tn_ok(const GemmArgs& a) {
     return a.vec_a && a.vec_b && (a.M % 4) == 0 && (a.N % 4) == 0 && a.M >= 4 && a.N >= 4 &&
            a.M <= ZERO_PAGE_FLOATS && a.N <= ZERO_PAGE_FLOATS && zero_page() != nullptr;
 }
+
+#ifdef GLF_STAMPS
+static void* stamps_buffer() {
+    static void* p = [] { void* q = nullptr; (void)hipMalloc(&q, 8192); (void)hipMemset(q, 0, 8192); return q; }();
+    return p;
+}
+extern "C" int glf_debug_stamps(void* host_out) {          // [8 waves][16 iterations][8] s_memtime values of the LAST NT launch
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpy(host_out, stamps_buffer(), 8192, hipMemcpyDeviceToHost);
+}
+#endif
 
 int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
     GemmArgs a = a0;
@@ -1294,29 +1476,34 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     }
     a.tiles_m = (int)tiles_m;
     dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
-    static const bool m16 = [] { const char* e = getenv("GLF_MFMA16"); return e ? e[0] != '0' : GLF_MFMA16_DEFAULT; }();
     static const int prio = [] { const char* e = getenv("GLF_SETPRIO"); return e ? (e[0] != '0') : GLF_SETPRIO_DEFAULT; }();
     static const int group_m = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : GLF_GROUP_M_DEFAULT; }();
     a.flags = prio | ((group_m & 0xff) << 8);
-#define GLF_LAUNCH_ROWS(G, NP_, M_, BP_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, M_, BP_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
-    const bool bp = a.Bh != nullptr && a.Bl != nullptr;          // pre-split B planes (32x32x16 kernels only)
+    const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
+#ifdef GLF_STAMPS
+    a.partial = reinterpret_cast<float*>(stamps_buffer());
+#endif
+#define GLF_LAUNCH_ROWS(G, NP_, PA_, PB_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, false, PB_, false, false, PA_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
+#define GLF_ROWS_P(G, NP_)                                                                     \
+    { if (pa && pb) GLF_LAUNCH_ROWS(G, NP_, true, true); else if (pa) GLF_LAUNCH_ROWS(G, NP_, true, false); \
+      else if (pb) GLF_LAUNCH_ROWS(G, NP_, false, true); else GLF_LAUNCH_ROWS(G, NP_, false, false); }
+#ifdef GLF_EXPERIMENTS
+    static const bool m16 = [] { const char* e = getenv("GLF_MFMA16"); return e ? e[0] != '0' : GLF_MFMA16_DEFAULT; }();
     static const bool deep = [] { const char* e = getenv("GLF_DEEP"); return e ? e[0] != '0' : GLF_DEEP_DEFAULT; }();
     static const bool ping = [] { const char* e = getenv("GLF_PING"); return e ? e[0] != '0' : GLF_PING_DEFAULT; }();
-    if (nprod == 3 && ping && !bp && !m16) {
-        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-    } else if (nprod == 3 && deep && !bp && !m16) {
-        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-    } else if (nprod == 3) {
-        if (bp) { if (gather) GLF_LAUNCH_ROWS(true, 3, false, true); else GLF_LAUNCH_ROWS(false, 3, false, true); }
-        else if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 3, true, false); else GLF_LAUNCH_ROWS(false, 3, true, false); }
-        else { if (gather) GLF_LAUNCH_ROWS(true, 3, false, false); else GLF_LAUNCH_ROWS(false, 3, false, false); }
-    } else {
-        if (bp) { if (gather) GLF_LAUNCH_ROWS(true, 1, false, true); else GLF_LAUNCH_ROWS(false, 1, false, true); }
-        else if (m16) { if (gather) GLF_LAUNCH_ROWS(true, 1, true, false); else GLF_LAUNCH_ROWS(false, 1, true, false); }
-        else { if (gather) GLF_LAUNCH_ROWS(true, 1, false, false); else GLF_LAUNCH_ROWS(false, 1, false, false); }
+    if (nprod == 3 && !pa && !pb && (ping || deep || m16)) {
+        if (ping) { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+                    else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
+        else if (deep) { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+                         else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
+        else { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, true, false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+               else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, true, false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
+        return check_launch("gemm_nt(f16x3, experiment)");
     }
+#endif
+    if (nprod == 3) { if (gather) GLF_ROWS_P(true, 3) else GLF_ROWS_P(false, 3) }
+    else { if (gather) GLF_ROWS_P(true, 1) else GLF_ROWS_P(false, 1) }
+#undef GLF_ROWS_P
 #undef GLF_LAUNCH_ROWS
     return check_launch("gemm_nt(f16x3, 256x128)");
 }
@@ -1324,25 +1511,23 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
 int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
     GemmArgs a = a0;
     a.zeros = zero_page();
-    if (a.M > BM) {                     // 256-wide tiles: re-derive the grid
+    const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
+    const bool wide = a.M > BM;             // 256-wide tiles: re-derive the grid
+    dim3 g2 = grid;
+    if (wide) {
         a.tiles_m = (a.M + TM8 - 1) / TM8;
-        dim3 g2((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
-        if (nprod == 3) {
-            if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true, 3>), g2, dim3(NT8), SMEM_TN_H8, s, a);
-            else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false, 3>), g2, dim3(NT8), SMEM_TN_H8, s, a);
-        } else {
-            if (gather) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<true, 1>), g2, dim3(NT8), SMEM_TN_H8, s, a);
-            else hipLaunchKernelGGL((gemm_tn_f16s8_kernel<false, 1>), g2, dim3(NT8), SMEM_TN_H8, s, a);
-        }
-        return check_launch("gemm_tn(f16x3, 256x128)");
+        g2 = dim3((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
     }
-    if (nprod == 3) {
-        if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true, 3>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
-        else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false, 3>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
-    } else {
-        if (gather) hipLaunchKernelGGL((gemm_tn_f16s_kernel<true, 1>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
-        else hipLaunchKernelGGL((gemm_tn_f16s_kernel<false, 1>), grid, dim3(NTHREADS), SMEM_TN_H, s, a);
-    }
+#define GLF_LAUNCH_TN(G, NP_, PA_, PB_)                                                                                        \
+    { if (wide) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), g2, dim3(NT8), SMEM_TN_H8, s, a);                 \
+      else hipLaunchKernelGGL((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), g2, dim3(NTHREADS), SMEM_TN_H, s, a); }
+#define GLF_TN_P(G, NP_)                                                                       \
+    { if (pa && pb) GLF_LAUNCH_TN(G, NP_, true, true) else if (pa) GLF_LAUNCH_TN(G, NP_, true, false) \
+      else if (pb) GLF_LAUNCH_TN(G, NP_, false, true) else GLF_LAUNCH_TN(G, NP_, false, false) }
+    if (nprod == 3) { if (gather) GLF_TN_P(true, 3) else GLF_TN_P(false, 3) }
+    else { if (gather) GLF_TN_P(true, 1) else GLF_TN_P(false, 1) }
+#undef GLF_TN_P
+#undef GLF_LAUNCH_TN
     return check_launch("gemm_tn(f16x3)");
 }
 

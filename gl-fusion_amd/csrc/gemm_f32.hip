@@ -700,13 +700,14 @@ extern "C" int glf_amax(const float* x, int64_t rows, int cols, int64_t ld, floa
     return glf::launch_amax(x, rows, cols, ld, aligned16(x) && (ld % 4 == 0), out, glf::S(stream));
 }
 
-extern "C" int glf_split_f16_planes(const float* x, int64_t n, const float* amax, void* h, void* l, glf_stream_t stream) {
+extern "C" int glf_split_f16_packed(const float* x, int64_t rows, int cols, int64_t ld, const float* amax, float* out, int64_t ldo,
+                                    glf_stream_t stream) {
     if (int rc = glf::ensure_init()) return rc;
-    GLF_REQUIRE(x && amax && h && l, GLF_ERR_NULL, "split_f16_planes: null argument");
-    GLF_REQUIRE(n > 0 && n % 4 == 0, GLF_ERR_BAD_SHAPE, "split_f16_planes: n must be a positive multiple of 4");
-    GLF_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(h) & 7u) == 0 && (reinterpret_cast<uintptr_t>(l) & 7u) == 0, GLF_ERR_BAD_SHAPE,
-                "split_f16_planes: x must be 16-byte, h and l 8-byte aligned");
-    return glf::launch_split_planes(x, n, amax, h, l, glf::S(stream));
+    GLF_REQUIRE(x && amax && out, GLF_ERR_NULL, "split_f16_packed: null argument");
+    GLF_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ld >= cols && ldo >= cols, GLF_ERR_BAD_SHAPE,
+                "split_f16_packed: cols and the row strides must be multiples of 4");
+    GLF_REQUIRE(aligned16(x) && aligned16(out), GLF_ERR_BAD_SHAPE, "split_f16_packed: x and out must be 16-byte aligned");
+    return glf::launch_split_packed(x, rows, cols, ld, amax, out, ldo, glf::S(stream));
 }
 
 extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, float* C,
@@ -733,14 +734,9 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     GLF_REQUIRE(!p->colstats || (prec >= 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
                 "glf_gemm_nt: colstats is honoured by the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands, no rect = 1, batch 1)");
     if (prec == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
-    if (a.Bh || a.Bl) {
-        GLF_REQUIRE(a.Bh && a.Bl && prec >= 2 && glf::f16s_rows_ok(a) && p->amax_b != nullptr, GLF_ERR_UNSUPPORTED,
-                    "glf_gemm_nt: b_planes need both planes, precision 3 / 4, the aligned fast path and the amax_b they were split with");
-        GLF_REQUIRE(p->ldb % 4 == 0 && p->tap_stride_b % 2 == 0 && p->batch_stride_b % 2 == 0 &&
-                    (reinterpret_cast<uintptr_t>(a.Bh) & 7u) == 0 && (reinterpret_cast<uintptr_t>(a.Bl) & 7u) == 0 &&
-                    ((reinterpret_cast<uintptr_t>(a.Bl) - reinterpret_cast<uintptr_t>(a.Bh)) & 3u) == 0, GLF_ERR_BAD_SHAPE,
-                    "glf_gemm_nt: b_planes need ldb %% 4 == 0, even tap / batch strides and 8-byte aligned planes");
-    }
+    if (p->a_presplit || p->b_presplit)
+        GLF_REQUIRE(prec >= 2 && glf::f16s_rows_ok(a) && (!p->a_presplit || p->amax_a) && (!p->b_presplit || p->amax_b), GLF_ERR_UNSUPPORTED,
+                    "glf_gemm_nt: a pre-split operand needs precision 3 / 4, the aligned fast path and the amax it was split with");
     if (prec >= 2 && glf::f16s_rows_ok(a)) {
         if (int rc = self_amax(a, p, false, glf::S(stream))) return rc;
         return glf::launch_rows_f16s(a, grid, p->gather != 0, prec == 2 ? 3 : 1, glf::S(stream));
@@ -804,6 +800,9 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
         GLF_REQUIRE(aligned16(p->workspace), GLF_ERR_WORKSPACE, "gemm_tn: workspace must be 16-byte aligned");
         a.partial = p->workspace;
     }
+    if (p->a_presplit || p->b_presplit)
+        GLF_REQUIRE(prec >= 2 && glf::f16s_tn_ok(a) && (!p->a_presplit || p->amax_a) && (!p->b_presplit || p->amax_b), GLF_ERR_UNSUPPORTED,
+                    "glf_gemm_tn: a pre-split operand needs precision 3 / 4, the aligned fast path and the amax it was split with");
     int rc;
     if (prec == 1 && glf::bf16s_tn_ok(a)) {
         rc = glf::launch_tn_bf16s(a, grid, p->gather != 0, glf::S(stream));

@@ -25,7 +25,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
 from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
-                  tn_needs_zero, transpose2d, weight_T, weight_planes, zeros)
+                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, pick, zeros)
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
@@ -96,8 +96,9 @@ class TpaviFn(Function):
         am_x = amax_of(x)
         am_q = amax_slot(dev)                # max|qkv| from the epilogue: one bound for the theta | phi | g column slices
         am_wc = amax_of(Wcat)
-        gemm("nt", x, Wcat, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=am_wc, amax_c=am_q,
-             b_planes=weight_planes(Wcat, Wcat, "w", am_wc))
+        ok = nt_presplit_ok(c, c, c)
+        wb, pb = pick(Wcat, weight_packed(Wcat, Wcat, "w", am_wc) if ok else None, ok)
+        gemm("nt", x, wb, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=am_wc, amax_c=am_q, b_packed=pb)
         ctx.qkv_owner = th_w                      # parameter the stacked operand (and its cached transpose) is keyed on
         set_amax(qkv, am_q)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
@@ -136,8 +137,9 @@ class TpaviFn(Function):
 
         wz = torch.empty(rows, c, **f32)
         am_zw = amax_of(wz_w)
-        gemm("nt", y, zW, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=amax_of(y), amax_b=am_zw,
-             b_planes=weight_planes(zW, wz_w, "w", am_zw))
+        ok = nt_presplit_ok(ci, ci, ci)
+        wb, pb = pick(zW, weight_packed(zW, wz_w, "w", am_zw) if ok else None, ok)
+        gemm("nt", y, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=amax_of(y), amax_b=am_zw, b_packed=pb)
 
         mean = torch.empty(c, **f32)
         invstd = torch.empty(c, **f32)
@@ -195,8 +197,9 @@ class TpaviFn(Function):
         if split:
             am_dy_slot = amax_slot(dev)
             zWT, am_zw = weight_T(zW, wz_o), amax_of(wz_o)
-            gemm("nt", dwz, zWT, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
-                 amax_c=am_dy_slot, b_planes=weight_planes(zWT, wz_o, "T2", am_zw))
+            wb, pb = pick(zWT, weight_packed(zWT, wz_o, "T2", am_zw), nt_presplit_ok(c, c, c))
+            gemm("nt", dwz, wb, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
+                 amax_c=am_dy_slot, b_packed=pb)
             set_amax(dy, am_dy_slot)
         else:
             gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
@@ -261,8 +264,8 @@ class TpaviFn(Function):
         if split:
             WcatT = weight_T(Wcat, Wcat)                        # cached with the stacked operand (one rebuild per weight update)
             am_wc = amax_of(Wcat)
-            gemm("nt", dqkv, WcatT, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=am_wc,
-                 b_planes=weight_planes(WcatT, Wcat, "T2", am_wc))
+            wb, pb = pick(WcatT, weight_packed(WcatT, Wcat, "T2", am_wc), nt_presplit_ok(c3, c3, c3))
+            gemm("nt", dqkv, wb, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=am_wc, b_packed=pb)
         else:
             gemm("nn", dqkv, Wcat, dx, M=rows, N=c, K=c3, lda=c3, ldb=c, ldc=c, accumulate=True)
         dx = dx.view_as(x)

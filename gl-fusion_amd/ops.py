@@ -146,11 +146,12 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
          split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
          amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None,
-         colstats: Optional[torch.Tensor] = None, b_planes: Optional[torch.Tensor] = None) -> None:
+         colstats: Optional[torch.Tensor] = None, a_packed: bool = False, b_packed: bool = False) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
     amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library);
     amax_c: a slot from amax_slot() that receives max|C written| (ignored by rect / split > 1 / non-f16x3 calls -- pass
-    it only to calls that store C directly)."""
+    it only to calls that store C directly).
+    a_packed / b_packed: A / B is the packed pre-split image packed_of() made with the same amax_a / amax_b."""
     p = GemmParams()
     p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
     p.taps, p.tap_mask, p.tap_stride_b, p.gather = taps, mask, tap_stride_b, gather
@@ -163,9 +164,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
     p.precision = _PREC[0] + 1
-    if b_planes is not None and mode == "nt" and amax_b is not None and K % 32 == 0:
-        # B (a weight layout) pre-split into fp16 planes [2][numel] with the scale of amax_b: not re-split in every tile
-        p.b_planes_h, p.b_planes_l = _p(b_planes[0]), _p(b_planes[1])
+    p.a_presplit, p.b_presplit = int(a_packed), int(b_packed)
     ws = None
     if mode == "tn" and split > 1 and TWO_STAGE_SPLITK:
         # two-stage reduction: the slices store partial sums, a second kernel adds them in a fixed order -- no atomics, no
@@ -333,27 +332,70 @@ def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.
     return out
 
 
-# Measured (C2 step, A/B in one run): 295.2 ms with pre-split weight planes against 292.5 ms without -- a third of the split
-# arithmetic gone, two 8-byte loads in place of one 16-byte load per piece: the kernel is bound by its load path, not by VALU.  Off.
-W_PLANES = os.environ.get("GLF_WPLANES", "0") != "0"
-_planes_cache = {}
+# Pre-split operands (split-fp16 precisions): an operand is split into its fp16 pieces ONCE, into a packed image of the same
+# size and strides, instead of in the staging path of every tile of every launch that reads it.
+PRESPLIT = os.environ.get("GLF_PRESPLIT", "1") != "0"
+_packed_cache = {}
 
 
-def weight_planes(layout: torch.Tensor, owner: torch.Tensor, tag: str, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """fp16 planes [2][numel] (h, l with x * s = h + 2^-11 l, s from `amax`) of a dense weight layout `layout` derived from the
-    parameter `owner` -- the B operand of an NT contraction under the split-fp16 precisions.  Split ONCE per weight update
-    (cached against the owner's version counter and the amax scalar it was scaled with) instead of in every tile of every
-    launch that uses the weight.  None when not applicable (other precisions, odd sizes, GLF_WPLANES=0)."""
-    if not W_PLANES or _PREC[0] < 2 or amax is None or layout.numel() % 4 != 0 or not layout.is_contiguous():
+def presplit_ok(t: torch.Tensor, amax: Optional[torch.Tensor]) -> bool:
+    return (PRESPLIT and _PREC[0] >= 2 and amax is not None and t.dim() >= 1 and t.shape[-1] % 4 == 0
+            and t.is_contiguous() and t.data_ptr() % 16 == 0)
+
+
+def packed_of(t: torch.Tensor, amax: torch.Tensor) -> torch.Tensor:
+    """The packed pre-split image of a contiguous fp32 tensor whose rows (last dim) hold a multiple of 4 elements: a tensor of
+    the same shape (declared fp32, holding fp16 pairs) to pass as A / B with a_packed / b_packed and the SAME amax."""
+    cols = t.shape[-1]
+    out = torch.empty_like(t)
+    check(lib.glf_split_f16_packed(_p(t), t.numel() // cols, cols, cols, _p(amax), _p(out), cols, _stream()), "split_f16_packed")
+    return out
+
+
+def weight_packed(layout: torch.Tensor, owner: torch.Tensor, tag: str, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """packed_of(layout) for a dense weight layout derived from the parameter `owner`, made once per weight update (cached
+    against the owner's version counter and the amax scalar it was scaled with).  None when not applicable."""
+    if not presplit_ok(layout, amax):
         return None
     key = (id(owner), tag)
-    hit = _planes_cache.get(key)
+    hit = _packed_cache.get(key)
     if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[3] == layout.data_ptr() and hit[4] is amax:
         return hit[2]
-    pl = torch.empty(2, layout.numel(), dtype=torch.float16, device=layout.device)
-    check(lib.glf_split_f16_planes(_p(layout), layout.numel(), _p(amax), _p(pl[0]), _p(pl[1]), _stream()), "split_f16_planes")
-    _planes_cache[key] = (weakref.ref(owner, lambda _r, k=key: _planes_cache.pop(k, None)), owner._version, pl, layout.data_ptr(), amax)
-    return pl
+    pk = packed_of(layout, amax)
+    _packed_cache[key] = (weakref.ref(owner, lambda _r, k=key: _packed_cache.pop(k, None)), owner._version, pk, layout.data_ptr(), amax)
+    return pk
+
+
+def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """packed_of(t) for an activation / gradient tensor, remembered on the tensor object (like its amax) so that every
+    contraction that reads it -- a conv input in the forward of each consumer and again in its weight gradient, an output
+    gradient in dgrad and wgrad -- shares one split pass.  None when not applicable."""
+    if not presplit_ok(t, amax):
+        return None
+    hit = getattr(t, "_glf_packed", None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and hit[2] is amax:
+        return hit[3]
+    pk = packed_of(t, amax)
+    try:
+        t._glf_packed = (t._version, t.data_ptr(), amax, pk)
+    except AttributeError:
+        pass
+    return pk
+
+
+def nt_presplit_ok(K: int, lda: int, ldb: int) -> bool:
+    """Mirror of the library's eligibility test for the aligned split-fp16 NT kernel (gemm_f16s.hip f16s_rows_ok)."""
+    return _PREC[0] >= 2 and K % 32 == 0 and 32 <= K <= (1 << 18) and lda % 4 == 0 and ldb % 4 == 0
+
+
+def tn_presplit_ok(M: int, N: int, lda: int, ldb: int) -> bool:
+    """Same for the TN kernel (f16s_tn_ok)."""
+    return _PREC[0] >= 2 and M % 4 == 0 and N % 4 == 0 and 4 <= M <= (1 << 18) and 4 <= N <= (1 << 18) and lda % 4 == 0 and ldb % 4 == 0
+
+
+def pick(t: torch.Tensor, packed: Optional[torch.Tensor], ok: bool):
+    """(operand, packed flag) for a gemm() call."""
+    return (packed, True) if (ok and packed is not None) else (t, False)
 
 
 _wT_cache = {}
@@ -488,11 +530,15 @@ class Conv2dFn(Function):
             zero_(y)
             if colstats is not None:
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
-        am_w = amax_of(weight)
-        gemm("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
+        am_w, am_x = amax_of(weight), amax_of(x)
+        ok = nt_presplit_ok(cin, cin, cin)
+        xa, pa = pick(x, act_packed(x, am_x) if ok else None, ok)
+        wb, pb = pick(wt, weight_packed(wt, weight, "w", am_w) if ok else None, ok)
+        gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
-             amax_a=amax_of(x), amax_b=am_w, colstats=colstats, b_planes=weight_planes(wt, weight, "w", am_w))
+             amax_a=am_x, amax_b=am_w, colstats=colstats, a_packed=pa, b_packed=pb)
         ctx.save_for_backward(x, wt)
+        ctx.x_packed = (xa, am_x) if pa else None      # the weight gradient reads the same image
         ctx.join = getattr(x, "_glf_join", None) if plain else None
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
@@ -532,10 +578,13 @@ class Conv2dFn(Function):
                     # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
                     am_dx = amax_slot(dx.device) if acc else None
                     wT = tap_major_T(ctx.weight_ref)
-                    gemm("nt", dy, wT, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
+                    ok = nt_presplit_ok(cout, cout, cout)
+                    da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                    wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
+                    gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                          taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
                          geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect,
-                         amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx, b_planes=weight_planes(wT, ctx.weight_ref, "wT", am_w))
+                         amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx, a_packed=pa, b_packed=pb)
                     if acc:
                         dx._glf_amax = None
                         set_amax(dx, am_dx)            # the maximum of the SUM, from the accumulating epilogue
@@ -554,10 +603,14 @@ class Conv2dFn(Function):
             split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
             full = mask == (1 << taps) - 1
             dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
-            gemm("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+            ok = tn_presplit_ok(cout, cin, cout, cin)
+            am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
+            da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+            xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else (act_packed(x, am_x) if ok else None), ok)
+            gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
                  geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,
-                 amax_a=am_dy, amax_b=amax_of(x))
+                 amax_a=am_dy, amax_b=am_x, a_packed=pa, b_packed=pb)
             if taps == 1:
                 dw = dwt.view(wshape)
             else:
@@ -613,8 +666,10 @@ class ConvCatFn(Function):
         if ctx.cat:
             y = torch.empty(*t0.shape[:-1], cout, dtype=torch.float32, device=t0.device)
             am_w = amax_of(weight)
-            gemm("nt", t0, w2, y, M=rows, N=cout, K=ctot, lda=ctot, ldb=ctot, ldc=cout, bias=bias,
-                 amax_a=amax_of(t0), amax_b=am_w, b_planes=weight_planes(w2, weight, "w", am_w))
+            ok = nt_presplit_ok(ctot, ctot, ctot)
+            wb, pb = pick(w2, weight_packed(w2, weight, "w", am_w) if ok else None, ok)
+            gemm("nt", t0, wb, y, M=rows, N=cout, K=ctot, lda=ctot, ldb=ctot, ldc=cout, bias=bias,
+                 amax_a=amax_of(t0), amax_b=am_w, b_packed=pb)
             ctx.save_for_backward(w2, *xs)
             ctx.wshape = tuple(weight.shape)
             ctx.weight_ref = weight
@@ -658,8 +713,11 @@ class ConvCatFn(Function):
                 am_dc = amax_slot(dy.device)
                 if split_mode() and cout % 32 == 0:
                     w2T = weight_T(w2, ctx.weight_ref)
-                    gemm("nt", dy, w2T, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
-                         amax_a=am_dy, amax_b=am_w, amax_c=am_dc, b_planes=weight_planes(w2T, ctx.weight_ref, "T2", am_w))
+                    ok = nt_presplit_ok(cout, cout, cout)
+                    da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                    wb, pb = pick(w2T, weight_packed(w2T, ctx.weight_ref, "T2", am_w) if ok else None, ok)
+                    gemm("nt", da, wb, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
+                         amax_a=am_dy, amax_b=am_w, amax_c=am_dc, a_packed=pa, b_packed=pb)
                 else:
                     am_dc = None
                     gemm("nn", dy, w2, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=ctot, ldc=ctot)
@@ -674,8 +732,10 @@ class ConvCatFn(Function):
                 split = _tn_split(rows, cout, ctot, 1)
                 if tn_needs_zero(split):
                     zero_(dw)
-                gemm("tn", dy, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
-                     amax_a=am_dy, amax_b=amax_of(t0))
+                ok = tn_presplit_ok(cout, ctot, cout, ctot)
+                da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                gemm("tn", da, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
+                     amax_a=am_dy, amax_b=amax_of(t0), a_packed=pa)
             return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
         for i, t in enumerate(xs):
             ck = t.shape[-1]

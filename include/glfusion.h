@@ -126,10 +126,12 @@ typedef struct {
                                 /* sums there and a second kernel adds them in a fixed order: no float atomics, C need   */
                                 /* not be zero-filled, results are bitwise reproducible.  Without it (NULL) the slices   */
                                 /* meet in float atomics and C must be zero-filled (or hold the value to add to).        */
-    const void* b_planes_h;     /* glf_gemm_nt, precision 3 / 4, optional: the B operand PRE-SPLIT into two fp16 planes   */
-    const void* b_planes_l;     /* (glf_split_f16_planes with the SAME amax_b; element indexing of B: ldb, tap and batch  */
-                                /* strides unchanged, all even).  B itself is then not read.  For operands that are      */
-                                /* reused across calls -- weights: split once per update instead of in every tile.       */
+    int32_t a_presplit;         /* precision 3 / 4 only: 1 = the A (B) pointer is not fp32 data but its packed pre-split   */
+    int32_t b_presplit;         /* image written by glf_split_f16_packed with the SAME amax_a (amax_b): same byte size,     */
+                                /* strides and addressing as the fp32 operand, every 16-byte group of four elements holding */
+                                /* {h0..h3, l0..l3} (fp16).  The kernels then skip the split in their staging path: an       */
+                                /* operand read by many tiles / launches (activations across column tiles, weights across   */
+                                /* row tiles, a conv input again in its weight gradient) is split once.                     */
     int32_t precision;          /* contraction precision of THIS call: 0 = the process default (glf_set_precision), */
                                 /* 1 = exact fp32, 2 = split-bf16 x6, 3 = split-fp16 x3, 4 = fp16 x1 (= 1 + the modes of */
                                 /* glf_set_precision).  Two models with different precisions can share a process.   */
@@ -137,10 +139,11 @@ typedef struct {
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
 int glf_amax(const float* x, int64_t rows, int cols, int64_t ld, float* out, glf_stream_t stream);
-/* h[i], l[i] (fp16, n elements each, n % 4 == 0, 16-byte aligned x / 8-byte aligned h, l) = the two planes of x[i] * s,
- * s the power of two the precision-3 kernels derive from *amax (a device float >= max|x|): x * s = h + 2^-11 l.
- * For glf_gemm_params.b_planes_h / _l. */
-int glf_split_f16_planes(const float* x, int64_t n, const float* amax, void* h, void* l, glf_stream_t stream);
+/* out = packed pre-split image of x [rows][cols] (row strides ld / ldo in floats; cols, ld, ldo % 4 == 0, 16-byte
+ * aligned): every float4 {x0..x3} -> {h0..h3, l0..l3} fp16 with x * s = h + 2^-11 l, s the power of two the precision-3
+ * kernels derive from *amax (a device float >= max|x|).  For glf_gemm_params.a_presplit / b_presplit. */
+int glf_split_f16_packed(const float* x, int64_t rows, int cols, int64_t ld, const float* amax, float* out, int64_t ldo,
+                         glf_stream_t stream);
 
 /* A[m][k] (k contiguous, rows gathered per `gather`), B_tap[n][k] (k contiguous: torch's
  * [Cout][Cin] weight layout per tap), C[m][n].  Replaces F.conv2d / nn.Conv3d(1x1x1) forward:

@@ -18,15 +18,29 @@ rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
 
 SHAPES = [("nt", 150528, 3072, 2048), ("nt", 150528, 2048, 1024), ("nt", 50176, 2048, 512), ("nt", 50176, 512, 2048),
           ("nt", 50176, 256, 1024), ("nt", 50176, 1024, 256), ("tn", 3072, 2048, 150528), ("tn", 2048, 512, 50176)]
+PACK = os.environ.get("PROBE_PACK", "")            # e.g. "ab": which operands go in pre-split
+LDPAD = int(os.environ.get("PROBE_LDPAD", "0"))    # NT shapes: row stride K + LDPAD floats (is a power-of-two stride a problem?)
+if os.environ.get("PROBE_SHAPES"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["PROBE_SHAPES"].split(",")]
 for mode, M, N, K in SHAPES:
     if mode == "nt":
-        A, B, C = rnd(M, K), rnd(N, K), torch.empty(M, N, device=dev)
-        run = lambda: ops.gemm("nt", A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=ops.amax_of(A), amax_b=ops.amax_of(B))
+        A, B, C = rnd(M, K + LDPAD), rnd(N, K + LDPAD), torch.empty(M, N, device=dev)
     else:
-        A, B = rnd(K, M), rnd(K, N)
+        A, B, C = rnd(K, M), rnd(K, N), torch.zeros(M, N, device=dev)
+    ama, amb = ops.amax_of(A), ops.amax_of(B)
+    pa, pb = "a" in PACK and ama is not None, "b" in PACK and amb is not None
+    Ax = ops.packed_of(A, ama) if pa else A
+    Bx = ops.packed_of(B, amb) if pb else B
+    if mode == "nt":
+        run = lambda X=Ax, Y=Bx, pa=pa, pb=pb: ops.gemm("nt", X, Y, C, M=M, N=N, K=K, lda=K + LDPAD, ldb=K + LDPAD, ldc=N, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
+    else:
         sp = ops._tn_split(K, M, N, 1)
-        C = torch.zeros(M, N, device=dev)
-        run = lambda: ops.gemm("tn", A, B, C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ops.amax_of(A), amax_b=ops.amax_of(B))
+        run = lambda X=Ax, Y=Bx, pa=pa, pb=pb: ops.gemm("tn", X, Y, C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
+    if pa or pb:                                   # the pre-split path must reproduce the in-kernel split bit for bit
+        run(A, B, False, False)
+        ref = C.clone()
+        run()
+        assert torch.equal(ref, C), f"pre-split result differs: {(ref - C).abs().max().item()}"
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -34,5 +48,5 @@ for mode, M, N, K in SHAPES:
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"{prec} {mode} M={M} N={N} K={K}: {dt * 1e3:.3f} ms  {2.0 * M * N * K / dt / 1e12:.1f} TF fp32-equivalent", flush=True)
-    del A, B, C
+    print(f"{prec} pack={PACK or '-'} ldpad={LDPAD} {mode} M={M} N={N} K={K}: {dt * 1e3:.3f} ms  {2.0 * M * N * K / dt / 1e12:.1f} TF fp32-equivalent", flush=True)
+    del A, B, C, Ax, Bx

@@ -418,6 +418,70 @@ def test_conv2d_real_shapes_fwd_dgrad_wgrad(ops, cfg):
     assert _rel_l2(wd.grad, wt.grad) <= 5e-5
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("cfg", [(3, 28, 28, 64, 96, 1, 1, 0, 1, True), (2, 28, 28, 128, 64, 3, 1, 2, 2, True), (2, 28, 28, 256, 32, 3, 1, 24, 24, False),
+                                 (2, 56, 56, 32, 64, 3, 2, 1, 1, True), (2, 28, 28, 512, 64, 3, 1, 12, 12, False),
+                                 (4, 28, 28, 256, 512, 1, 1, 0, 1, True)])
+def test_presplit_operands_reproduce_in_kernel_split_bitwise(cfg, prec):
+    """Operands handed over in the packed pre-split image (glf_split_f16_packed; A and B of the NT kernels, A and B of the
+    TN kernels, plain / gathered / per-tap rectangles / regions) must give the SAME BITS as the same call splitting in its
+    staging path: forward, dgrad and wgrad of a conv with the host-side switch on and off.  The convs that run as per-tap
+    rectangles add their taps with float atomics in run-to-run order: those are held to 1e-6 of the tensor's maximum."""
+    from glfusion_amd import ops as _ops
+    n, h, w, cin, cout, k, stride, pad, dil, bitwise = cfg
+    x = rnd(n, h, w, cin, seed=70).to(DEV)
+    wt = (rnd(cout, cin, k, k, seed=71) / np.sqrt(cin * k * k)).to(DEV)
+    keep = _ops.PRESPLIT
+    outs = []
+    _ops.set_precision(prec)
+    try:
+        for on in (False, True):
+            _ops.PRESPLIT = on
+            xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+            y = _ops.conv2d(xd, wd, None, stride, pad, dil)
+            gy = rnd(*y.shape, seed=72).to(DEV)
+            y.backward(gy)
+            outs.append((y.detach().clone(), xd.grad.clone(), wd.grad.clone()))
+        assert getattr(xd, "_glf_packed", None) is not None, "the pre-split path did not run"
+    finally:
+        _ops.PRESPLIT = keep
+        _ops.set_precision("f32")
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        err = (a - b).abs().max().item()
+        if bitwise:
+            assert torch.equal(a, b), f"{name}: pre-split differs from in-kernel split by {err:.3e}"
+        else:
+            assert err <= 1e-6 * a.abs().max().item(), f"{name}: pre-split differs from in-kernel split by {err:.3e}"
+
+
+def test_split_f16_packed_layout_and_errors():
+    """glf_split_f16_packed: every float4 becomes {h0..h3, l0..l3} with x * s = h + 2^-11 l; bad strides are refused."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd._lib import lib
+    _ops.set_precision("f16x3")
+    try:
+        x = (rnd(37, 64, seed=73) * 3.0).to(DEV)
+        am = _ops.amax_of(x)
+        pk = _ops.packed_of(x, am)
+        torch.cuda.synchronize()
+        halves = pk.view(torch.float16).view(37, 16, 8).double().cpu()
+        x64, amax = x.double().cpu(), float(am.item())
+        # the library's scale: the power of two that brings the maximum into [2^13, 2^14)
+        recon = None
+        for e in range(-40, 40):
+            s = 2.0 ** e
+            r = ((halves[..., :4] + halves[..., 4:] * 2.0 ** -11) / s).reshape(37, 64)
+            if (r - x64).abs().max() <= 2.0 ** -21 * amax:
+                recon = e
+                break
+        assert recon is not None, "no power-of-two scale reconstructs x from the packed image to 2^-21 of its maximum"
+        assert lib.glf_split_f16_packed(x.data_ptr(), 37, 62, 64, am.data_ptr(), pk.data_ptr(), 64, None) != 0
+        assert lib.glf_split_f16_packed(x.data_ptr(), 37, 64, 62, am.data_ptr(), pk.data_ptr(), 64, None) != 0
+        assert lib.glf_split_f16_packed(None, 37, 64, 64, am.data_ptr(), pk.data_ptr(), 64, None) != 0
+    finally:
+        _ops.set_precision("f32")
+
+
 # ------------------------------------------------------------------------------------------ f16x3 range adversaries
 def test_f16x3_outlier_and_small_view_operands():
     """The split-fp16 kernels scale each operand by ONE power of two taken from its maximum.  Adversaries: (a) a gradient
