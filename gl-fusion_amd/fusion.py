@@ -25,7 +25,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
 from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
-                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, pick, zeros)
+                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, pick, zeros)
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
@@ -98,7 +98,10 @@ class TpaviFn(Function):
         am_wc = amax_of(Wcat)
         ok = nt_presplit_ok(c, c, c)
         wb, pb = pick(Wcat, weight_packed(Wcat, Wcat, "w", am_wc) if ok else None, ok)
-        gemm("nt", x, wb, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=am_wc, amax_c=am_q, b_packed=pb)
+        xa, pa = pick(x, act_packed(x, am_x) if ok else None, ok)       # read again by the weight gradient of the projections
+        gemm("nt", xa, wb, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=am_wc, amax_c=am_q,
+             a_packed=pa, b_packed=pb)
+        ctx.x_packed = (xa, am_x) if pa else None
         ctx.qkv_owner = th_w                      # parameter the stacked operand (and its cached transpose) is keyed on
         set_amax(qkv, am_q)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
@@ -139,7 +142,10 @@ class TpaviFn(Function):
         am_zw = amax_of(wz_w)
         ok = nt_presplit_ok(ci, ci, ci)
         wb, pb = pick(zW, weight_packed(zW, wz_w, "w", am_zw) if ok else None, ok)
-        gemm("nt", y, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=amax_of(y), amax_b=am_zw, b_packed=pb)
+        am_y = amax_of(y)
+        ya, pa = pick(y, act_packed(y, am_y) if ok else None, ok)
+        gemm("nt", ya, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=am_y, amax_b=am_zw, a_packed=pa, b_packed=pb)
+        ctx.y_packed = (ya, am_y) if pa else None
 
         mean = torch.empty(c, **f32)
         invstd = torch.empty(c, **f32)
@@ -189,7 +195,11 @@ class TpaviFn(Function):
         sp = _tn_split(rows, c, ci, 1)
         dzW = (zeros if tn_needs_zero(sp) else torch.empty)(c, ci, **f32)
         am_dwz, am_q = amax_of(dwz), amax_of(qkv)
-        gemm("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=amax_of(y))
+        ok = tn_presplit_ok(c, ci, c, ci)
+        dwz_a, pa = pick(dwz, act_packed(dwz, am_dwz) if ok else None, ok)       # shared with the NT contraction below
+        am_y = ctx.y_packed[1] if ctx.y_packed is not None else amax_of(y)
+        yb, pb = pick(y, ctx.y_packed[0] if ctx.y_packed is not None else None, ok)
+        gemm("tn", dwz_a, yb, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=am_y, a_packed=pa, b_packed=pb)
         dzb = colsum(dwz, rows, c)
         split = split_mode() and ci % 32 == 0 and c % 32 == 0
         (wz_o,) = ctx.owners
@@ -197,13 +207,16 @@ class TpaviFn(Function):
         if split:
             am_dy_slot = amax_slot(dev)
             zWT, am_zw = weight_T(zW, wz_o), amax_of(wz_o)
-            wb, pb = pick(zWT, weight_packed(zWT, wz_o, "T2", am_zw), nt_presplit_ok(c, c, c))
-            gemm("nt", dwz, wb, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
-                 amax_c=am_dy_slot, b_packed=pb)
+            ok = nt_presplit_ok(c, c, c)
+            wb, pb = pick(zWT, weight_packed(zWT, wz_o, "T2", am_zw), ok)
+            da, pa = pick(dwz, act_packed(dwz, am_dwz) if ok else None, ok)
+            gemm("nt", da, wb, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
+                 amax_c=am_dy_slot, a_packed=pa, b_packed=pb)
+            del da
             set_amax(dy, am_dy_slot)
         else:
             gemm("nn", dwz, zW, dy, M=rows, N=ci, K=c, lda=c, ldb=ci, ldc=ci)
-        del dwz
+        del dwz, dwz_a
 
         dqkv = torch.empty(rows, c3, **f32)                   # [d theta | d phi | d g], row stride 3*ci
         am_dq_slot = amax_slot(dev)                           # its three writers (below) all report into one slot
@@ -256,7 +269,11 @@ class TpaviFn(Function):
         sp = _tn_split(rows, c3, c, 1)
         dWcat = (zeros if tn_needs_zero(sp) else torch.empty)(c3, c, **f32)
         am_dq = amax_of(dqkv)
-        gemm("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp, amax_a=am_dq, amax_b=amax_of(x))
+        ok = tn_presplit_ok(c3, c, c3, c)
+        dq_a, pa = pick(dqkv, act_packed(dqkv, am_dq) if ok else None, ok)
+        am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
+        xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
+        gemm("tn", dq_a, xb, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp, amax_a=am_dq, amax_b=am_x, a_packed=pa, b_packed=pb)
         dbcat = colsum(dqkv, rows, c3)
         grads_w = [dWcat[i * ci:(i + 1) * ci].reshape(pshape) for i in range(3)]
         grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
@@ -264,8 +281,11 @@ class TpaviFn(Function):
         if split:
             WcatT = weight_T(Wcat, Wcat)                        # cached with the stacked operand (one rebuild per weight update)
             am_wc = amax_of(Wcat)
-            wb, pb = pick(WcatT, weight_packed(WcatT, Wcat, "T2", am_wc), nt_presplit_ok(c3, c3, c3))
-            gemm("nt", dqkv, wb, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=am_wc, b_packed=pb)
+            ok = nt_presplit_ok(c3, c3, c3)
+            wb, pb = pick(WcatT, weight_packed(WcatT, Wcat, "T2", am_wc), ok)
+            da, pa = pick(dqkv, act_packed(dqkv, am_dq) if ok else None, ok)
+            gemm("nt", da, wb, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=am_wc,
+                 a_packed=pa, b_packed=pb)
         else:
             gemm("nn", dqkv, Wcat, dx, M=rows, N=c, K=c3, lda=c3, ldb=c, ldc=c, accumulate=True)
         dx = dx.view_as(x)

@@ -335,6 +335,11 @@ def transpose2d(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.
 # Pre-split operands (split-fp16 precisions): an operand is split into its fp16 pieces ONCE, into a packed image of the same
 # size and strides, instead of in the staging path of every tile of every launch that reads it.
 PRESPLIT = os.environ.get("GLF_PRESPLIT", "1") != "0"
+# An activation / gradient tensor is worth its split pass (one read + one write of the tensor) only if the contractions that
+# read it re-split it often enough: the pass costs ~ rows x K x 8 bytes of HBM traffic, the NT kernel saves ~14 % and the
+# weight-gradient kernel ~15 % of a time proportional to rows x K x (output columns x taps).  Break-even measured near
+# columns x taps = 1000.  (Weights are always pre-split: once per update, cached.)
+PRESPLIT_MIN_COLS = int(os.environ.get("GLF_PRESPLIT_MIN_COLS", "1024"))
 _packed_cache = {}
 
 
@@ -532,7 +537,8 @@ class Conv2dFn(Function):
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         am_w, am_x = amax_of(weight), amax_of(x)
         ok = nt_presplit_ok(cin, cin, cin)
-        xa, pa = pick(x, act_packed(x, am_x) if ok else None, ok)
+        ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or getattr(x, "_glf_packed", None) is not None)
+        xa, pa = pick(x, act_packed(x, am_x) if ok_x else None, ok_x)
         wb, pb = pick(wt, weight_packed(wt, weight, "w", am_w) if ok else None, ok)
         gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
@@ -579,7 +585,8 @@ class Conv2dFn(Function):
                     am_dx = amax_slot(dx.device) if acc else None
                     wT = tap_major_T(ctx.weight_ref)
                     ok = nt_presplit_ok(cout, cout, cout)
-                    da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                    ok_dy = ok and cin * bin(mask).count("1") >= PRESPLIT_MIN_COLS
+                    da, pa = pick(dy, act_packed(dy, am_dy) if ok_dy else None, ok_dy)
                     wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
                     gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                          taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
@@ -605,8 +612,10 @@ class Conv2dFn(Function):
             dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
             ok = tn_presplit_ok(cout, cin, cout, cin)
             am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
-            da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
-            xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else (act_packed(x, am_x) if ok else None), ok)
+            # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
+            ok_dy = ok and (getattr(dy, "_glf_packed", None) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
+            da, pa = pick(dy, act_packed(dy, am_dy) if ok_dy else None, ok_dy)
+            xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
             gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
                  geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,

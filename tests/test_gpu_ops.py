@@ -431,10 +431,11 @@ def test_presplit_operands_reproduce_in_kernel_split_bitwise(cfg, prec):
     n, h, w, cin, cout, k, stride, pad, dil, bitwise = cfg
     x = rnd(n, h, w, cin, seed=70).to(DEV)
     wt = (rnd(cout, cin, k, k, seed=71) / np.sqrt(cin * k * k)).to(DEV)
-    keep = _ops.PRESPLIT
+    keep = (_ops.PRESPLIT, _ops.PRESPLIT_MIN_COLS)
     outs = []
     _ops.set_precision(prec)
     try:
+        _ops.PRESPLIT_MIN_COLS = 0              # every eligible operand, whatever the host-side break-even rule says
         for on in (False, True):
             _ops.PRESPLIT = on
             xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
@@ -444,7 +445,7 @@ def test_presplit_operands_reproduce_in_kernel_split_bitwise(cfg, prec):
             outs.append((y.detach().clone(), xd.grad.clone(), wd.grad.clone()))
         assert getattr(xd, "_glf_packed", None) is not None, "the pre-split path did not run"
     finally:
-        _ops.PRESPLIT = keep
+        _ops.PRESPLIT, _ops.PRESPLIT_MIN_COLS = keep
         _ops.set_precision("f32")
     for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
         err = (a - b).abs().max().item()
