@@ -106,6 +106,9 @@ __device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& i
 // ----------------------------------------------------------------------------------------------------------
 constexpr int BM8 = 256;
 constexpr int NT8 = 512;
+#ifndef GLF_IL_ALL          // 1: the slot-interleaved iteration also when neither operand is pre-split
+#define GLF_IL_ALL 1
+#endif
 constexpr int PL_A8 = BM8 * 64, PL_B8 = BN * 64;
 constexpr int BUF8 = 2 * PL_A8 + 2 * PL_B8;
 #ifdef GLF_STAMPS       // diagnostic build (profiles/ubench/stamps.sh): per-wave s_memtime stamps of 16 main-loop iterations of one workgroup
@@ -449,13 +452,16 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             __syncthreads();                                                                                  \
             GLF_STAMP_FLUSH()                                                                                 \
         }
-// Both operands pre-split: the iteration has no conversion arithmetic left, only 24 MFMAs, 16 fragment reads, 6 LDS stores
-// and 6 global loads per wave.  They are placed one by one (GLF_IL_*: a slot = the memory operations issued behind one MFMA,
-// pinned by sched_barriers): a wave issues in order, so whatever sits between two of ITS MFMAs delays the second one unless it
-// fits the ~24 issue cycles the first leaves free.  Slots 1-4: the k-step-1 fragments (two reads each); 5: pointer advance;
-// 6-11: one staging piece each (store the registers loaded an iteration ago, refill them); 12-15: the next tile's k-step-0
-// fragments into registers whose last reader has issued; MFMAs 16-24 run with nothing behind them, so every LDS operation
-// has landed when the barrier is reached.
+// The iteration, instruction by instruction (GLF_IL_*: a slot = what is issued behind one MFMA, pinned by sched_barriers).
+// A wave issues in order, so whatever sits between two of ITS MFMAs delays the second one unless it fits the ~24 issue cycles
+// the first leaves free; in bursts (the compiler's choice: all fragment reads, then six MFMAs, then a whole conversion
+// piece ...) the matrix pipe idles behind every burst -- in-kernel stamps showed 2 575 cycles per iteration for 1 536 cycles
+// of MFMA work, and the eight waves' LDS / global bursts colliding.  Per wave and iteration: 24 MFMAs, 16 fragment reads,
+// 6 staging pieces.  Slots 1-4: the k-step-1 fragments (two reads each); 5: pointer advance; 6-19: the staging pieces -- a
+// pre-split operand's piece is one slot (LDS store of the registers loaded an iteration ago + their refill), a piece that
+// still has to be split is cut into three (scale + high halves | residual | low halves + store + refill: 4-6 VALU each);
+// 12-18 also carry the next tile's k-step-0 fragments, each into registers whose last reader has issued; the last MFMAs run
+// with nothing behind them, so every LDS operation has landed when the barrier is reached.
 #define GLF_IL_RD(P, w_, base_, off_) P##w_ = *reinterpret_cast<const f16x8*>((base_) + (off_));
 #define GLF_IL_PIN() __builtin_amdgcn_sched_barrier(0);
 #define GLF_IL_MM(c_, a_, b_) c_ = GLF_MFMA_F16(a_, b_, c_);
@@ -466,6 +472,51 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             if (NP == 3) { GLF_IL_MM(m1, al, b1h) GLF_IL_PIN() } S4_ GLF_IL_PIN()                             \
             if (NP == 3) { GLF_IL_MM(m0, ah, b0l) GLF_IL_PIN() } S5_ GLF_IL_PIN()                             \
             if (NP == 3) { GLF_IL_MM(m1, ah, b1l) GLF_IL_PIN() } S6_ GLF_IL_PIN()
+        // the three stages of a piece that is split here (SRC_ = its float4, SC_ = the operand's scale)
+        f32x2 sx01_, sx23_, sr01_, sr23_;
+        f16x2 sh01_, sh23_;
+#define GLF_IL_ST1(SRC_, SC_)                                                                                 \
+            { const f32x2 s2_ = {SC_, SC_}; const f32x2 v01_ = {SRC_.x, SRC_.y}, v23_ = {SRC_.z, SRC_.w};     \
+              sx01_ = v01_ * s2_; sx23_ = v23_ * s2_;                                                         \
+              sh01_ = __builtin_convertvector(sx01_, f16x2); sh23_ = __builtin_convertvector(sx23_, f16x2); }
+#define GLF_IL_ST2()                                                                                          \
+            { const f32x2 k2_ = {2048.f, 2048.f};                                                             \
+              sr01_ = (sx01_ - __builtin_convertvector(sh01_, f32x2)) * k2_;                                  \
+              sr23_ = (sx23_ - __builtin_convertvector(sh23_, f32x2)) * k2_; }
+#define GLF_IL_ST3(DST_, PL_)                                                                                 \
+            { *reinterpret_cast<f16x4*>(DST_) = __builtin_shufflevector(sh01_, sh23_, 0, 1, 2, 3);            \
+              if (NP == 3) *reinterpret_cast<f16x4*>((DST_) + (PL_)) =                                        \
+                  __builtin_shufflevector(__builtin_convertvector(sr01_, f16x2), __builtin_convertvector(sr23_, f16x2), 0, 1, 2, 3); }
+        // stage ST_ (1..3) of A piece J / B piece J of the tile being staged into buffer `wr`
+#define GLF_IL_A(J, ST_, CONV_, LOAD_)                                                                        \
+            if (PA) { if (ST_ == 3) { GLF_H8_PIECE(J, wr, CONV_, LOAD_) } }                                   \
+            else if (CONV_) {                                                                                 \
+                if (ST_ == 1) GLF_IL_ST1(ra[J], sc_a)                                                         \
+                else if (ST_ == 2) GLF_IL_ST2()                                                               \
+                else { GLF_IL_ST3(smem_s + wr * BUF8 + st_off + J * 64 * 64, PL_A8)                           \
+                       if (LOAD_) ra[J] = *reinterpret_cast<const float4*>(pa[J]); }                          \
+            }
+#define GLF_IL_B(J, ST_, CONV_, LOAD_)                                                                        \
+            if (BP) { if (ST_ == 3) { GLF_H8_PIECE(4 + J, wr, CONV_, LOAD_) } }                               \
+            else if (CONV_) {                                                                                 \
+                if (ST_ == 1) GLF_IL_ST1(rb[J], sc_b)                                                         \
+                else if (ST_ == 2) GLF_IL_ST2()                                                               \
+                else { GLF_IL_ST3(smem_s + wr * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64, PL_B8)               \
+                       if (LOAD_) GLF_H8_LOAD_B(J) }                                                          \
+            }
+// staging work item i_ of the iteration: the A pieces' stages, then the B pieces' (one item per pre-split piece, three per
+// piece split here) -- items sit in consecutive slots from slot 6 on, so pre-split operands finish their LDS stores early
+#define GLF_IL_ITEM(I_, CONV_, LOAD_)                                                                         \
+            {                                                                                                 \
+                constexpr int nA_ = PA ? 4 : 12, nB_ = BP ? 2 : 6, i_ = (I_);                                 \
+                if constexpr (i_ < nA_) {                                                                     \
+                    constexpr int j_ = PA ? i_ : i_ / 3, st_ = PA ? 3 : i_ % 3 + 1;                           \
+                    GLF_IL_A(j_, st_, CONV_, LOAD_)                                                           \
+                } else if constexpr (i_ < nA_ + nB_) {                                                        \
+                    constexpr int k_ = i_ - nA_, j_ = BP ? k_ : k_ / 3, st_ = BP ? 3 : k_ % 3 + 1;            \
+                    GLF_IL_B(j_, st_, CONV_, LOAD_)                                                           \
+                }                                                                                             \
+            }
 #define GLF_H8_BODY_IL(CONV_, LOAD_, NEXT_)                                                                   \
         {                                                                                                     \
             GLF_STAMP(0)                                                                                      \
@@ -480,24 +531,32 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                 { if (NP == 3) { GLF_IL_RD(g, b0l, gb_, PL_B8) GLF_IL_RD(g, b1l, gb_, 32 * 64 + PL_B8) } },   \
                 { GLF_IL_RD(g, a1h, ga_, 32 * 64) if (NP == 3) { GLF_IL_RD(g, a1l, ga_, 32 * 64 + PL_A8) } }, \
                 { if (LOAD_) advance(); },                                                                    \
-                { GLF_H8_PIECE(0, wr, CONV_, LOAD_) })                                                        \
+                { GLF_IL_ITEM(0, CONV_, LOAD_) })                                                             \
             GLF_STAMP(1)                                                                                      \
             GLF_IL_ROW(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l,                                \
-                { GLF_H8_PIECE(1, wr, CONV_, LOAD_) },                                                        \
-                { GLF_H8_PIECE(2, wr, CONV_, LOAD_) },                                                        \
-                { GLF_H8_PIECE(3, wr, CONV_, LOAD_) },                                                        \
-                { GLF_H8_PIECE(4, wr, CONV_, LOAD_) },                                                        \
-                { GLF_H8_PIECE(5, wr, CONV_, LOAD_) },                                                        \
-                { if (NEXT_) { GLF_IL_RD(f, a0h, na_, 0) if (NP == 3) { GLF_IL_RD(f, a0l, na_, PL_A8) } } })  \
+                { GLF_IL_ITEM(1, CONV_, LOAD_) },                                                             \
+                { GLF_IL_ITEM(2, CONV_, LOAD_) },                                                             \
+                { GLF_IL_ITEM(3, CONV_, LOAD_) },                                                             \
+                { GLF_IL_ITEM(4, CONV_, LOAD_) },                                                             \
+                { GLF_IL_ITEM(5, CONV_, LOAD_) },                                                             \
+                { GLF_IL_ITEM(6, CONV_, LOAD_) if (NEXT_) { GLF_IL_RD(f, a0h, na_, 0) if (NP == 3) { GLF_IL_RD(f, a0l, na_, PL_A8) } } }) \
             if (NP != 3) { ga0l = ga0h; gb0l = gb0h; gb1l = gb1h; ga1l = ga1h; }                              \
             GLF_STAMP(2)                                                                                      \
             GLF_IL_ROW(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l,                                \
-                { if (NEXT_) { GLF_IL_RD(f, b0h, nb_, 0) GLF_IL_RD(f, b1h, nb_, 32 * 64) } },                 \
-                { if (NEXT_ && NP == 3) { GLF_IL_RD(f, b0l, nb_, PL_B8) GLF_IL_RD(f, b1l, nb_, 32 * 64 + PL_B8) } }, \
-                { if (NEXT_) { GLF_IL_RD(f, a1h, na_, 32 * 64) if (NP == 3) { GLF_IL_RD(f, a1l, na_, 32 * 64 + PL_A8) } } }, \
-                {}, {}, {})                                                                                   \
+                { GLF_IL_ITEM(7, CONV_, LOAD_) if (NEXT_) { GLF_IL_RD(f, b0h, nb_, 0) GLF_IL_RD(f, b1h, nb_, 32 * 64) } }, \
+                { GLF_IL_ITEM(8, CONV_, LOAD_) if (NEXT_ && NP == 3) { GLF_IL_RD(f, b0l, nb_, PL_B8) GLF_IL_RD(f, b1l, nb_, 32 * 64 + PL_B8) } }, \
+                { GLF_IL_ITEM(9, CONV_, LOAD_) if (NEXT_) { GLF_IL_RD(f, a1h, na_, 32 * 64) if (NP == 3) { GLF_IL_RD(f, a1l, na_, 32 * 64 + PL_A8) } } }, \
+                { GLF_IL_ITEM(10, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(11, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(12, CONV_, LOAD_) })                                                            \
             GLF_STAMP(3)                                                                                      \
-            GLF_IL_ROW(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l, {}, {}, {}, {}, {}, {})        \
+            GLF_IL_ROW(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l,                                \
+                { GLF_IL_ITEM(13, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(14, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(15, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(16, CONV_, LOAD_) },                                                            \
+                { GLF_IL_ITEM(17, CONV_, LOAD_) },                                                            \
+                {})                                                                                           \
             if (NP != 3 && NEXT_) { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }                     \
             { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
             GLF_STAMP(4)                                                                                      \
@@ -508,7 +567,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 #if defined(GLF_STAMPS) && GLF_STAMPS == 2
         wg_t1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (PA && BP) {
+        if (PA || BP || GLF_IL_ALL) {
             for (; it + 3 < ntiles; ++it) GLF_H8_BODY_IL(true, true, true)
             if (it + 2 < ntiles) { GLF_H8_BODY_IL(true, false, true) ++it; }
             if (it + 1 < ntiles) { GLF_H8_BODY_IL(false, false, true) ++it; }
