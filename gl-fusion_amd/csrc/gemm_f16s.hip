@@ -1163,19 +1163,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// tn kernel, 8 waves: tile 256 (A columns) x 128 (B columns) x 32 rows, two LDS buffers, the software pipeline of the
-// rows kernel (tile t multiplied out of buffer t&1 while tile t+1 is converted into the other buffer in six pieces
-// between MFMA groups and tile t+2 is in flight from global memory).  Planes are [r][cols] with 576-byte (A) and
-// 320-byte (B) rows: both strides are 16 mod 64 dwords, which keeps the transposing ds_read_b64_tr_b16 fragment
-// reads and the 8-byte staging writes conflict-free.  Row coordinates (n, y, x) advance incrementally by 32 per
-// tile; rows outside the slice, in the conv padding or in the column overhang are loaded from the zero page.
+// tn kernel, 8 waves: tile 256 (A columns) x 128 (B columns) x 32 rows, THREE LDS buffers and the slot-interleaved software
+// pipeline of the rows kernel (tile t multiplied out of buffer t%3 with its k-step-0 fragments read before the barrier,
+// tile t+2 converted into buffer (t+2)%3, tile t+3 in flight from global memory).  Planes are [r][cols] with dense rows
+// (512 bytes for A, 256 for B: 48 KB per buffer) and the 64-byte chunks of a row XOR-swizzled with (row & 3): the
+// transposing ds_read_b64_tr_b16 fragment reads (four rows x 64 bytes per half wave) and the 8-byte staging writes are
+// conflict-free without padding.  Row coordinates (n, y, x) advance incrementally by 32 per tile; rows outside the slice,
+// in the conv padding or in the column overhang are loaded from the zero page.
 // Used when M > 128 (otherwise half of the 256-wide tile would be idle and the 128 x 128 kernel above runs).
 // ----------------------------------------------------------------------------------------------------------
 constexpr int TM8 = 256;
-constexpr int RSA = 576, RSB = 320;
+constexpr int RSA = 512, RSB = 256;
 constexpr int PA8 = 32 * RSA, PB8 = 32 * RSB;
 constexpr int TBUF8 = 2 * PA8 + 2 * PB8;
-constexpr size_t SMEM_TN_H8 = 2 * TBUF8;
+constexpr size_t SMEM_TN_H8 = 3 * TBUF8;
 
 template <bool GATHER, int NP, bool PA = false, bool PB = false>
 __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs args) {
@@ -1197,7 +1198,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform, and known to be: everything derived from it stays in SGPRs
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
@@ -1230,14 +1232,17 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     if (r0 >= r1) return;
     const int ntiles = (r1 - r0 + BK - 1) / BK;
 
-    // staging map: A tile 32 x 256 floats = 4 float4 per thread (rows ra0 + 8 j, column ca), B tile 32 x 128 = 2 (rows rb0 + 16 j)
-    const int ca = tid & 63, ra0 = tid >> 6;
+    // staging map: A tile 32 x 256 floats = 4 float4 per thread (rows ra0 + 8 j, column ca), B tile 32 x 128 = 2 (rows rb0 + 16 j).
+    // ra0 is the wave index: an A row, its pixel coordinates and its base pointer are WAVE-UNIFORM and live in SGPRs (the
+    // kernel sits at the 256-register limit: per-lane copies of that state spilled into the main loop, and a scratch reload
+    // between the global loads turns every s_waitcnt vmcnt(5) into vmcnt(0)); a lane adds only its column offset.  Lanes in the
+    // column overhang (m0 >= M) read column 0 instead: they feed accumulator columns that are never stored.
+    const int ca = tid & 63, ra0 = wave;
     const int cb = tid & 31, rb0 = tid >> 5;
     const int m0 = tm * TM8 + 4 * ca, n0 = tn * BN + 4 * cb;
     const bool a_col_ok = m0 < pM, b_col_ok = n0 < pN;
-    const float* __restrict__ Ac = A + (a_col_ok ? m0 : 0);
+    const unsigned a_col = a_col_ok ? (unsigned)m0 : 0u;
     const float* __restrict__ Bc = B + (b_col_ok ? n0 : 0);
-    const float* __restrict__ za = p_zero + (a_col_ok ? m0 : 0);
     const float* __restrict__ zb = p_zero + (b_col_ok ? n0 : 0);
 
     // current row index and (for conv gathers) its pixel coordinates inside the rectangle, per staged row
@@ -1265,16 +1270,16 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
             bn[j] = n; by[j] = yy; bx[j] = rem - yy * r_w;
         }
     }
-    const float* pa[4];
+    const float* pa[4];          // row bases (uniform); the lane's column offset a_col is added at the load
     const float* pb[2];
     // pointers of the NEXT tile to load, then step every row by 32
     auto advance = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = ar[j] < r1 && a_col_ok;
+            const bool ok = ar[j] < r1;
             long long arow = ar[j];
             if (GATHER && p_rect) arow = ((long long)an[j] * g_hd + r_y0 + ay[j]) * g_wd + r_x0 + ax[j];
-            pa[j] = ok ? Ac + arow * p_lda : za;
+            pa[j] = ok ? A + arow * p_lda : p_zero;
             ar[j] += BK;
             if (GATHER && p_rect) {
                 ax[j] += BK;
@@ -1304,7 +1309,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};
     float4 ra[4], rb[2];
-    const int st_a = ra0 * RSA + ca * 8, st_b = rb0 * RSB + cb * 8;
+    // swizzled staging offsets: 8-byte unit ca of row ra0 + 8 j (A) / unit cb of row rb0 + 16 j (B): (row & 3) is the thread's own
+    const int st_a = ra0 * RSA + ((((ca >> 3) ^ (ra0 & 3)) << 6) | ((ca & 7) << 3));
+    const int st_b = rb0 * RSB + ((((cb >> 3) ^ (rb0 & 3)) << 6) | ((cb & 7) << 3));
 #define GLF_T8_CONV_A(J, buf_)                                                                               \
     {                                                                                                        \
         const SplitH s = PA ? unpack4h(ra[J]) : split4h(ra[J], sc_a);                                        \
@@ -1317,20 +1324,25 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         unsigned char* d = smem_s + (buf_) * TBUF8 + 2 * PA8 + st_b + J * 16 * RSB;                          \
         *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PB8) = s.l;           \
     }
+    // (a pre-split piece: the store stays ahead of the load that refills its registers -- see GLF_H8_PIN)
 #define GLF_T8_PIECE(pc, buf_, conv_, load_)                                                                 \
     switch (pc) {                                                                                            \
-        case 0: if (conv_) GLF_T8_CONV_A(0, buf_) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0]); break; \
-        case 1: if (conv_) GLF_T8_CONV_A(1, buf_) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1]); break; \
-        case 2: if (conv_) GLF_T8_CONV_A(2, buf_) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2]); break; \
-        case 3: if (conv_) GLF_T8_CONV_A(3, buf_) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3]); break; \
-        case 4: if (conv_) GLF_T8_CONV_B(0, buf_) if (load_) rb[0] = *reinterpret_cast<const float4*>(pb[0]); break; \
-        default: if (conv_) GLF_T8_CONV_B(1, buf_) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); break; \
+        case 0: if (conv_) GLF_T8_CONV_A(0, buf_) GLF_H8_PIN(PA) if (load_) ra[0] = *reinterpret_cast<const float4*>(pa[0] + a_col); GLF_H8_PIN(PA) break; \
+        case 1: if (conv_) GLF_T8_CONV_A(1, buf_) GLF_H8_PIN(PA) if (load_) ra[1] = *reinterpret_cast<const float4*>(pa[1] + a_col); GLF_H8_PIN(PA) break; \
+        case 2: if (conv_) GLF_T8_CONV_A(2, buf_) GLF_H8_PIN(PA) if (load_) ra[2] = *reinterpret_cast<const float4*>(pa[2] + a_col); GLF_H8_PIN(PA) break; \
+        case 3: if (conv_) GLF_T8_CONV_A(3, buf_) GLF_H8_PIN(PA) if (load_) ra[3] = *reinterpret_cast<const float4*>(pa[3] + a_col); GLF_H8_PIN(PA) break; \
+        case 4: if (conv_) GLF_T8_CONV_B(0, buf_) GLF_H8_PIN(PB) if (load_) rb[0] = *reinterpret_cast<const float4*>(pb[0]); GLF_H8_PIN(PB) break; \
+        default: if (conv_) GLF_T8_CONV_B(1, buf_) GLF_H8_PIN(PB) if (load_) rb[1] = *reinterpret_cast<const float4*>(pb[1]); GLF_H8_PIN(PB) break; \
     }
 
-    // transposing fragment reads (see gemm_bf16s.hip): group g of 16 lanes: columns 16*(g&1).., k half g>>1
+    // transposing fragment reads (see gemm_bf16s.hip): group g of 16 lanes: columns 16*(g&1).., k half g>>1; the lane's rows
+    // are q and q + 4 (mod 8), so its swizzle key is q
     const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int tr_a = (8 * (grp >> 1) + q) * RSA + (16 * (grp & 1) + 4 * pp) * 2 + wm * 2;
-    const int tr_b = (8 * (grp >> 1) + q) * RSB + (16 * (grp & 1) + 4 * pp) * 2 + wn * 2;
+    const int tr_in = 32 * (grp & 1) + 8 * pp;
+    const int tr_a0 = (8 * (grp >> 1) + q) * RSA + ((((wm >> 5) + 0) ^ q) << 6) + tr_in;       // columns wm .. wm + 31
+    const int tr_a1 = (8 * (grp >> 1) + q) * RSA + ((((wm >> 5) + 1) ^ q) << 6) + tr_in;       // columns wm + 32 .. wm + 63
+    const int tr_b0 = (8 * (grp >> 1) + q) * RSB + ((((wn >> 5) + 0) ^ q) << 6) + tr_in;
+    const int tr_b1 = (8 * (grp >> 1) + q) * RSB + ((((wn >> 5) + 1) ^ q) << 6) + tr_in;
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 #define GLF_T8_FRAG(base, RS_, dst)                                                                         \
     {                                                                                                       \
@@ -1340,8 +1352,12 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         const s16x8_ both_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                     \
         dst = __builtin_bit_cast(f16x8, both_);                                                             \
     }
+    // fragment w_ of set P (f = k-step 0, g = k-step 1) of the tile in buffer buf_
+#define GLF_TL_A(P, w_, buf_, ks_, off_, pl_) GLF_T8_FRAG(smem_s + (buf_) * TBUF8 + (ks_) * 16 * RSA + (off_) + (pl_), RSA, P##w_)
+#define GLF_TL_B(P, w_, buf_, ks_, off_, pl_) GLF_T8_FRAG(smem_s + (buf_) * TBUF8 + 2 * PA8 + (ks_) * 16 * RSB + (off_) + (pl_), RSB, P##w_)
 
-    // prologue: tile 0 -> buffer 0, tile 1 raw in registers
+    if (ntiles <= 0) return;
+    // prologue: tiles 0 and 1 -> buffers 0 and 1, tile 2 raw in registers, the k-step-0 fragments of tile 0 in f*
     advance();
 #pragma unroll
     for (int pc = 0; pc < 6; ++pc) { GLF_T8_PIECE(pc, 0, false, true) }
@@ -1350,38 +1366,91 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         if (more) advance();
 #pragma unroll
         for (int pc = 0; pc < 6; ++pc) { GLF_T8_PIECE(pc, 0, true, more) }
+        if (more) {
+            const bool more2 = ntiles > 2;
+            if (more2) advance();
+#pragma unroll
+            for (int pc = 0; pc < 6; ++pc) { GLF_T8_PIECE(pc, 1, true, more2) }
+        }
     }
     __syncthreads();
-#define GLF_T8_BODY(CONV_, LOAD_)                                                                             \
+    f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l;
+    GLF_TL_B(f, b0h, 0, 0, tr_b0, 0) GLF_TL_B(f, b1h, 0, 0, tr_b1, 0) GLF_TL_A(f, a0h, 0, 0, tr_a0, 0) GLF_TL_A(f, a1h, 0, 0, tr_a1, 0)
+    if (NP == 3) {
+        GLF_TL_A(f, a0l, 0, 0, tr_a0, PA8) GLF_TL_B(f, b0l, 0, 0, tr_b0, PB8) GLF_TL_B(f, b1l, 0, 0, tr_b1, PB8) GLF_TL_A(f, a1l, 0, 0, tr_a1, PA8)
+    } else { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }
+    int cur = 0, nxt = 1, wr = 2;           // LDS buffers of tile it, it+1, it+2
+    // staging work items as in the rows kernel (GLF_IL_ITEM): one slot per pre-split piece, three per piece split here
+    f32x2 sx01_, sx23_, sr01_, sr23_;
+    f16x2 sh01_, sh23_;
+#define GLF_TL_SA(J, ST_, CONV_, LOAD_)                                                                       \
+            if (PA) { if (ST_ == 3) { GLF_T8_PIECE(J, wr, CONV_, LOAD_) } }                                   \
+            else if (CONV_) {                                                                                 \
+                if (ST_ == 1) GLF_IL_ST1(ra[J], sc_a)                                                         \
+                else if (ST_ == 2) GLF_IL_ST2()                                                               \
+                else { GLF_IL_ST3(smem_s + wr * TBUF8 + st_a + J * 8 * RSA, PA8)                              \
+                       if (LOAD_) ra[J] = *reinterpret_cast<const float4*>(pa[J] + a_col); }                  \
+            }
+#define GLF_TL_SB(J, ST_, CONV_, LOAD_)                                                                       \
+            if (PB) { if (ST_ == 3) { GLF_T8_PIECE(4 + J, wr, CONV_, LOAD_) } }                               \
+            else if (CONV_) {                                                                                 \
+                if (ST_ == 1) GLF_IL_ST1(rb[J], sc_b)                                                         \
+                else if (ST_ == 2) GLF_IL_ST2()                                                               \
+                else { GLF_IL_ST3(smem_s + wr * TBUF8 + 2 * PA8 + st_b + J * 16 * RSB, PB8)                   \
+                       if (LOAD_) rb[J] = *reinterpret_cast<const float4*>(pb[J]); }                          \
+            }
+#define GLF_TL_ITEM(I_, CONV_, LOAD_)                                                                         \
+            {                                                                                                 \
+                constexpr int nA_ = PA ? 4 : 12, nB_ = PB ? 2 : 6, i_ = (I_);                                 \
+                if constexpr (i_ < nA_) {                                                                     \
+                    constexpr int j_ = PA ? i_ : i_ / 3, st_ = PA ? 3 : i_ % 3 + 1;                           \
+                    GLF_TL_SA(j_, st_, CONV_, LOAD_)                                                          \
+                } else if constexpr (i_ < nA_ + nB_) {                                                        \
+                    constexpr int k_ = i_ - nA_, j_ = PB ? k_ : k_ / 3, st_ = PB ? 3 : k_ % 3 + 1;            \
+                    GLF_TL_SB(j_, st_, CONV_, LOAD_)                                                          \
+                }                                                                                             \
+            }
+#define GLF_T8_BODY(CONV_, LOAD_, NEXT_)                                                                      \
     {                                                                                                         \
-        const int buf = it & 1;                                                                               \
-        if (LOAD_) advance();                                                                                 \
-        const unsigned char* ab = smem_s + buf * TBUF8 + tr_a;                                                \
-        const unsigned char* bb = smem_s + buf * TBUF8 + 2 * PA8 + tr_b;                                      \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
-            f16x8 b0h, b0l, b1h, b1l;                                                                         \
-            GLF_T8_FRAG(bb + s * 16 * RSB, RSB, b0h) GLF_T8_FRAG(bb + s * 16 * RSB + 64, RSB, b1h)            \
-            GLF_T8_FRAG(bb + s * 16 * RSB + PB8, RSB, b0l) GLF_T8_FRAG(bb + s * 16 * RSB + 64 + PB8, RSB, b1l) \
-            {                                                                                                 \
-                f16x8 ah, al;                                                                                 \
-                GLF_T8_FRAG(ab + s * 16 * RSA, RSA, ah) GLF_T8_FRAG(ab + s * 16 * RSA + PA8, RSA, al)         \
-                GLF_T8_PIECE(3 * s + 0, buf ^ 1, CONV_, LOAD_)                                                \
-                GLF_ROW3(c00, c01, m00, m01, ah, al, b0h, b0l, b1h, b1l)                                      \
-                GLF_T8_PIECE(3 * s + 1, buf ^ 1, CONV_, LOAD_)                                                \
-            }                                                                                                 \
-            {                                                                                                 \
-                f16x8 ah, al;                                                                                 \
-                GLF_T8_FRAG(ab + s * 16 * RSA + 64, RSA, ah) GLF_T8_FRAG(ab + s * 16 * RSA + 64 + PA8, RSA, al) \
-                GLF_ROW3(c10, c11, m10, m11, ah, al, b0h, b0l, b1h, b1l)                                      \
-                GLF_T8_PIECE(3 * s + 2, buf ^ 1, CONV_, LOAD_)                                                \
-            }                                                                                                 \
-        }                                                                                                     \
+        f16x8 gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;                                                 \
+        GLF_IL_ROW(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l,                                    \
+            { GLF_TL_B(g, b0h, cur, 1, tr_b0, 0) GLF_TL_A(g, a0h, cur, 1, tr_a0, 0) },                        \
+            { GLF_TL_B(g, b1h, cur, 1, tr_b1, 0) if (NP == 3) { GLF_TL_A(g, a0l, cur, 1, tr_a0, PA8) } },     \
+            { if (NP == 3) { GLF_TL_B(g, b0l, cur, 1, tr_b0, PB8) GLF_TL_B(g, b1l, cur, 1, tr_b1, PB8) } },   \
+            { GLF_TL_A(g, a1h, cur, 1, tr_a1, 0) if (NP == 3) { GLF_TL_A(g, a1l, cur, 1, tr_a1, PA8) } },     \
+            { if (LOAD_) advance(); },                                                                        \
+            { GLF_TL_ITEM(0, CONV_, LOAD_) })                                                                 \
+        GLF_IL_ROW(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l,                                    \
+            { GLF_TL_ITEM(1, CONV_, LOAD_) },                                                                 \
+            { GLF_TL_ITEM(2, CONV_, LOAD_) },                                                                 \
+            { GLF_TL_ITEM(3, CONV_, LOAD_) },                                                                 \
+            { GLF_TL_ITEM(4, CONV_, LOAD_) },                                                                 \
+            { GLF_TL_ITEM(5, CONV_, LOAD_) },                                                                 \
+            { GLF_TL_ITEM(6, CONV_, LOAD_) if (NEXT_) { GLF_TL_A(f, a0h, nxt, 0, tr_a0, 0) if (NP == 3) { GLF_TL_A(f, a0l, nxt, 0, tr_a0, PA8) } } }) \
+        if (NP != 3) { ga0l = ga0h; gb0l = gb0h; gb1l = gb1h; ga1l = ga1h; }                                  \
+        GLF_IL_ROW(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l,                                    \
+            { GLF_TL_ITEM(7, CONV_, LOAD_) if (NEXT_) { GLF_TL_B(f, b0h, nxt, 0, tr_b0, 0) GLF_TL_B(f, b1h, nxt, 0, tr_b1, 0) } }, \
+            { GLF_TL_ITEM(8, CONV_, LOAD_) if (NEXT_ && NP == 3) { GLF_TL_B(f, b0l, nxt, 0, tr_b0, PB8) GLF_TL_B(f, b1l, nxt, 0, tr_b1, PB8) } }, \
+            { GLF_TL_ITEM(9, CONV_, LOAD_) if (NEXT_) { GLF_TL_A(f, a1h, nxt, 0, tr_a1, 0) if (NP == 3) { GLF_TL_A(f, a1l, nxt, 0, tr_a1, PA8) } } }, \
+            { GLF_TL_ITEM(10, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(11, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(12, CONV_, LOAD_) })                                                                \
+        GLF_IL_ROW(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l,                                    \
+            { GLF_TL_ITEM(13, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(14, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(15, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(16, CONV_, LOAD_) },                                                                \
+            { GLF_TL_ITEM(17, CONV_, LOAD_) },                                                                \
+            {})                                                                                               \
+        if (NP != 3 && NEXT_) { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }                         \
+        { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                                 \
         __syncthreads();                                                                                      \
     }
     int it = 0;
-    for (; it + 2 < ntiles; ++it) GLF_T8_BODY(true, true)
-    if (it + 1 < ntiles) { GLF_T8_BODY(true, false) ++it; }
-    GLF_T8_BODY(false, false)
+    for (; it + 3 < ntiles; ++it) GLF_T8_BODY(true, true, true)
+    if (it + 2 < ntiles) { GLF_T8_BODY(true, false, true) ++it; }
+    if (it + 1 < ntiles) { GLF_T8_BODY(false, false, true) ++it; }
+    GLF_T8_BODY(false, false, false)
 
     const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
