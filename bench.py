@@ -228,13 +228,26 @@ def main():
             step()
         fence()
         t0 = time.perf_counter()
+        host = 0.0
         for _ in range(args.steps):
+            th = time.perf_counter()
             loss = step()
+            host += time.perf_counter() - th          # time the host spent enqueueing (step() does not synchronise)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         loss_val = float(loss)
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
+        if os.environ.get("GLF_BENCH_CPROFILE"):          # diagnostic: where the HOST time of a step goes (outside the timed region)
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(2):
+                step()
+            pr.disable()
+            fence()
+            with open(os.environ["GLF_BENCH_CPROFILE"] + "." + precision + ".txt", "w") as fh:
+                pstats.Stats(pr, stream=fh).sort_stats("tottime").print_stats(45)
         streams = ops.STREAMS
         ops.STREAMS = False
         step()
@@ -246,7 +259,7 @@ def main():
         fence()
         ops.PROFILER = None
         ops.STREAMS = streams
-        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps}
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host}
 
     def roofline_of(leg):
         precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
@@ -343,6 +356,7 @@ def main():
             "value": round(args.clips * world * args.steps / dt, 4),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "host_enqueue_ms_per_step": round(main_leg["host"] / args.steps * 1e3, 2),
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16": "f16 operands (amax-scaled, one MFMA per product), fp32 accumulate, fp32 storage: NOT fp32-equivalent "

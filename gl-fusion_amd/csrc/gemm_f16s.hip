@@ -1630,7 +1630,10 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     a.tiles_m = (int)tiles_m;
     dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
     static const int prio = [] { const char* e = getenv("GLF_SETPRIO"); return e ? (e[0] != '0') : GLF_SETPRIO_DEFAULT; }();
-    static const int group_m = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : GLF_GROUP_M_DEFAULT; }();
+    // tile order: groups of 4 row tiles x all column tiles once there are >= 8 column tiles (more of the streamed operands
+    // served from the XCD's L2: +2 % on the N >= 2048 shapes now that the loop is MFMA-bound; -2 % at 4 column tiles)
+    static const int group_m_env = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : -1; }();
+    const int group_m = group_m_env >= 0 ? group_m_env : (a.rect == 0 && a.tiles_n >= 8 ? 4 : 0);
     a.flags = prio | ((group_m & 0xff) << 8);
     const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
 #ifdef GLF_STAMPS

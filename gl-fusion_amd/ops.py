@@ -371,20 +371,40 @@ def weight_packed(layout: torch.Tensor, owner: torch.Tensor, tag: str, amax: Opt
     return pk
 
 
+def packed_hit(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The pre-split image already made of t (by an earlier consumer of this tensor object, or of another alias handed out by
+    fan_out), or None."""
+    hit = getattr(t, "_glf_packed", None)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and hit[2] is amax:
+        return hit[3]
+    share = getattr(t, "_glf_pack_share", None)          # the aliases of one fan_out share one image
+    if share is not None and share[0] is not None and share[0][0] == t.data_ptr() and share[0][1] is amax:
+        pk, made_on = share[0][2], share[0][3]
+        cur = torch.cuda.current_stream()
+        if made_on.cuda_stream != cur.cuda_stream:       # the aliases' consumers may sit on different side streams
+            cur.wait_stream(made_on)
+            pk.record_stream(cur)
+        return pk
+    return None
+
+
 def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """packed_of(t) for an activation / gradient tensor, remembered on the tensor object (like its amax) so that every
     contraction that reads it -- a conv input in the forward of each consumer and again in its weight gradient, an output
     gradient in dgrad and wgrad -- shares one split pass.  None when not applicable."""
     if not presplit_ok(t, amax):
         return None
-    hit = getattr(t, "_glf_packed", None)
-    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and hit[2] is amax:
-        return hit[3]
+    pk = packed_hit(t, amax)
+    if pk is not None:
+        return pk
     pk = packed_of(t, amax)
     try:
         t._glf_packed = (t._version, t.data_ptr(), amax, pk)
     except AttributeError:
         pass
+    share = getattr(t, "_glf_pack_share", None)
+    if share is not None:
+        share[0] = (t.data_ptr(), amax, pk, torch.cuda.current_stream())
     return pk
 
 
@@ -537,7 +557,7 @@ class Conv2dFn(Function):
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         am_w, am_x = amax_of(weight), amax_of(x)
         ok = nt_presplit_ok(cin, cin, cin)
-        ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or getattr(x, "_glf_packed", None) is not None)
+        ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or packed_hit(x, am_x) is not None)
         xa, pa = pick(x, act_packed(x, am_x) if ok_x else None, ok_x)
         wb, pb = pick(wt, weight_packed(wt, weight, "w", am_w) if ok else None, ok)
         gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
@@ -613,7 +633,7 @@ class Conv2dFn(Function):
             ok = tn_presplit_ok(cout, cin, cout, cin)
             am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
             # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
-            ok_dy = ok and (getattr(dy, "_glf_packed", None) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
+            ok_dy = ok and (packed_hit(dy, am_dy) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
             da, pa = pick(dy, act_packed(dy, am_dy) if ok_dy else None, ok_dy)
             xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
             gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
@@ -1095,8 +1115,10 @@ class FanOutFn(Function):
         ctx.k = k
         outs = tuple(x.view_as(x) for _ in range(k))
         am = amax_of(x)                       # one measurement (or the producer's by-product) serves every alias
+        share = [None]                        # ... and so does one pre-split image, whichever consumer makes it first
         for t in outs:
             set_amax(t, am)
+            t._glf_pack_share = share
         return outs
 
     @staticmethod
