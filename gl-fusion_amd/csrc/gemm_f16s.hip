@@ -106,6 +106,9 @@ __device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& i
 // ----------------------------------------------------------------------------------------------------------
 constexpr int BM8 = 256;
 constexpr int NT8 = 512;
+#ifndef GLF_MFMA16_PRESPLIT_DEFAULT
+#define GLF_MFMA16_PRESPLIT_DEFAULT 0
+#endif
 #ifndef GLF_IL_ALL          // 1: the slot-interleaved iteration also when neither operand is pre-split
 #define GLF_IL_ALL 1
 #endif
@@ -813,7 +816,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             if (NP == 3) dl = *reinterpret_cast<const f16x8*>(p_ + PL_B8); else dl = dh;                        \
         }
         f16x8 a0h, a0l, a1h, a1l, a2h, a2l, a3h, a3l, b0h, b0l, b1h, b1l, b2h, b2l, b3h, b3l;
-        GLF_M16_B(0, 0, b0h, b0l) GLF_M16_B(0, 1, b1h, b1l) GLF_M16_B(0, 2, b2h, b2l) GLF_M16_B(0, 3, b3h, b3l)
+        GLF_M16_B(0, 0, b0h, b0l) GLF_M16_B(0, 1, b1h, b1l) GLF_M16_B(0, 2, b2h, b2l)
+        if (!(PA && BP)) GLF_M16_B(0, 3, b3h, b3l)
         GLF_M16_A(0, 0, a0h, a0l) GLF_M16_A(0, 1, a1h, a1l)
         int cur = 0, nxt = 1, wr = 2;
         // Per iteration: slabs 0, 1 of A (loaded one iteration ahead) against all of B while slabs 2, 3 arrive; then slabs 2, 3
@@ -848,11 +852,44 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
             __syncthreads();                                                                                  \
         }
+        // Pre-split operands: the same products with everything else placed tile by tile (a slot = what is issued behind the
+        // three MFMAs of one 16 x 16 tile; sched_barriers pin it).  B slab 3 of the NEXT tile is not fetched before the barrier
+        // (its registers are busy until the last product) but in the first slot of the next iteration, three tiles before its
+        // first use: no LDS operation is younger than two tiles when the barrier is reached.
+#define GLF_M16_T(t, u, ah, al, bh, bl, SLOT_) GLF_M16_TILE(t, u, ah, al, bh, bl) GLF_IL_PIN() SLOT_ GLF_IL_PIN()
+#define GLF_M16_BODY_IL(CONV_, LOAD_, NEXT_)                                                                  \
+        {                                                                                                     \
+            GLF_M16_T(t00, u00, a0h, a0l, b0h, b0l, { GLF_M16_B(cur, 3, b3h, b3l) GLF_M16_A(cur, 2, a2h, a2l) }) \
+            GLF_M16_T(t01, u01, a0h, a0l, b1h, b1l, { GLF_M16_A(cur, 3, a3h, a3l) })                          \
+            GLF_M16_T(t02, u02, a0h, a0l, b2h, b2l, { if (LOAD_) advance(); })                                \
+            GLF_M16_T(t03, u03, a0h, a0l, b3h, b3l, { if (NEXT_) GLF_M16_A(nxt, 0, a0h, a0l) })               \
+            GLF_M16_T(t10, u10, a1h, a1l, b0h, b0l, { GLF_H8_PIECE(0, wr, CONV_, LOAD_) })                    \
+            GLF_M16_T(t11, u11, a1h, a1l, b1h, b1l, { GLF_H8_PIECE(1, wr, CONV_, LOAD_) })                    \
+            GLF_M16_T(t12, u12, a1h, a1l, b2h, b2l, { GLF_H8_PIECE(2, wr, CONV_, LOAD_) })                    \
+            GLF_M16_T(t13, u13, a1h, a1l, b3h, b3l, { GLF_H8_PIECE(3, wr, CONV_, LOAD_) })                    \
+            GLF_M16_T(t20, u20, a2h, a2l, b0h, b0l, { if (NEXT_) GLF_M16_A(nxt, 1, a1h, a1l) })               \
+            GLF_M16_T(t30, u30, a3h, a3l, b0h, b0l, { if (NEXT_) GLF_M16_B(nxt, 0, b0h, b0l) GLF_H8_PIECE(4, wr, CONV_, LOAD_) }) \
+            GLF_M16_T(t21, u21, a2h, a2l, b1h, b1l, { GLF_H8_PIECE(5, wr, CONV_, LOAD_) })                    \
+            GLF_M16_T(t31, u31, a3h, a3l, b1h, b1l, { if (NEXT_) GLF_M16_B(nxt, 1, b1h, b1l) })               \
+            GLF_M16_T(t22, u22, a2h, a2l, b2h, b2l, {})                                                       \
+            GLF_M16_T(t32, u32, a3h, a3l, b2h, b2l, { if (NEXT_) GLF_M16_B(nxt, 2, b2h, b2l) })               \
+            GLF_M16_T(t23, u23, a2h, a2l, b3h, b3l, {})                                                       \
+            GLF_M16_T(t33, u33, a3h, a3l, b3h, b3l, {})                                                       \
+            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
+            __syncthreads();                                                                                  \
+        }
         int it = 0;
-        for (; it + 3 < ntiles; ++it) GLF_M16_BODY(true, true, true)
-        if (it + 2 < ntiles) { GLF_M16_BODY(true, false, true) ++it; }
-        if (it + 1 < ntiles) { GLF_M16_BODY(false, false, true) ++it; }
-        GLF_M16_BODY(false, false, false)
+        if (PA && BP) {
+            for (; it + 3 < ntiles; ++it) GLF_M16_BODY_IL(true, true, true)
+            if (it + 2 < ntiles) { GLF_M16_BODY_IL(true, false, true) ++it; }
+            if (it + 1 < ntiles) { GLF_M16_BODY_IL(false, false, true) ++it; }
+            GLF_M16_BODY_IL(false, false, false)
+        } else {
+            for (; it + 3 < ntiles; ++it) GLF_M16_BODY(true, true, true)
+            if (it + 2 < ntiles) { GLF_M16_BODY(true, false, true) ++it; }
+            if (it + 1 < ntiles) { GLF_M16_BODY(false, false, true) ++it; }
+            GLF_M16_BODY(false, false, false)
+        }
     }
 
     float cmax = 0.f;
@@ -883,11 +920,21 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     // of rows -- 16 global_store_dwordx4 per lane instead of 64 one-dword stores.  The one-dword form took ~19 k cycles per
     // workgroup (in-kernel stamps, profiles/r02_stamps_*.txt): 13 % of a K = 2048 tile's time, 40 % of a K = 512 tile's,
     // with the matrix pipe idle (one workgroup per CU: nothing else runs meanwhile).
-    const bool wide_store = !M16 && p_rect != 1 && (p_ldc % 4) == 0 && (pN % 4) == 0 && (reinterpret_cast<size_t>(C) % 16) == 0 &&
+    const bool wide_store = p_rect != 1 && (p_ldc % 4) == 0 && (pN % 4) == 0 && (reinterpret_cast<size_t>(C) % 16) == 0 &&
                             (p_bsc % 4) == 0;
     if (wide_store) {
         float* tile = reinterpret_cast<float*>(smem_s) + wave * (64 * 64);
-        {
+        if (M16) {        // 16 x 16 tiles: element r of tile (i, j) is row 16 i + 4 (lane >> 4) + r, column 16 j + (lane & 15)
+            const int col_l = lane & 15, row_l = 4 * (lane >> 4);
+            auto park16 = [&](const f32x4& acc, int ti, int tj) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[(16 * ti + row_l + r) * 64 + 16 * tj + col_l] = acc[r];
+            };
+            park16(t00 + u00 * 0x1p-11f, 0, 0); park16(t01 + u01 * 0x1p-11f, 0, 1); park16(t02 + u02 * 0x1p-11f, 0, 2); park16(t03 + u03 * 0x1p-11f, 0, 3);
+            park16(t10 + u10 * 0x1p-11f, 1, 0); park16(t11 + u11 * 0x1p-11f, 1, 1); park16(t12 + u12 * 0x1p-11f, 1, 2); park16(t13 + u13 * 0x1p-11f, 1, 3);
+            park16(t20 + u20 * 0x1p-11f, 2, 0); park16(t21 + u21 * 0x1p-11f, 2, 1); park16(t22 + u22 * 0x1p-11f, 2, 2); park16(t23 + u23 * 0x1p-11f, 2, 3);
+            park16(t30 + u30 * 0x1p-11f, 3, 0); park16(t31 + u31 * 0x1p-11f, 3, 1); park16(t32 + u32 * 0x1p-11f, 3, 2); park16(t33 + u33 * 0x1p-11f, 3, 3);
+        } else {
             const int col_l = lane & 31, row_l = 4 * (lane >> 5);
             auto park = [&](const f32x16& acc, int ti, int tj) __attribute__((always_inline)) {
 #pragma unroll
@@ -1568,7 +1615,7 @@ int init_gemm_f16s_attrs() {
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
 #define SET_ROWS(G, NP_, PA_, PB_) SET_ATTR((gemm_rows_f16s8_kernel<G, NP_, false, PB_, false, false, PA_>), SMEM_ROWS_H8)
 #define SET_TN(G, NP_, PA_, PB_) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), SMEM_TN_H) SET_ATTR((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), SMEM_TN_H8)
-#define SET_ALL(G, NP_) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
+#define SET_ALL(G, NP_) SET_ATTR((gemm_rows_f16s8_kernel<G, 3, true, true, false, false, true>), SMEM_ROWS_H8) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
                         SET_TN(G, NP_, false, false) SET_TN(G, NP_, true, false) SET_TN(G, NP_, false, true) SET_TN(G, NP_, true, true)
     SET_ALL(false, 3) SET_ALL(true, 3) SET_ALL(false, 1) SET_ALL(true, 1)
 #ifdef GLF_EXPERIMENTS      // the measured-and-dropped variants of DESIGN.md section 8 (16x16x32 MFMA, deep prefetch, ping-pong)
@@ -1643,6 +1690,14 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
 #define GLF_ROWS_P(G, NP_)                                                                     \
     { if (pa && pb) GLF_LAUNCH_ROWS(G, NP_, true, true); else if (pa) GLF_LAUNCH_ROWS(G, NP_, true, false); \
       else if (pb) GLF_LAUNCH_ROWS(G, NP_, false, true); else GLF_LAUNCH_ROWS(G, NP_, false, false); }
+    // both operands pre-split, three products: the 16x16x32 MFMA form of the loop (same cycles per FLOP as 32x32x16; the chip
+    // holds a higher clock on it -- MI355X_MICROARCH.md, DVFS give-back item 7)
+    static const bool m16p = [] { const char* e = getenv("GLF_MFMA16_PRESPLIT"); return e ? e[0] != '0' : GLF_MFMA16_PRESPLIT_DEFAULT; }();
+    if (nprod == 3 && pa && pb && m16p) {
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, true, true, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, true, true, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        return check_launch("gemm_nt(f16x3, 16x16x32, pre-split)");
+    }
 #ifdef GLF_EXPERIMENTS
     static const bool m16 = [] { const char* e = getenv("GLF_MFMA16"); return e ? e[0] != '0' : GLF_MFMA16_DEFAULT; }();
     static const bool deep = [] { const char* e = getenv("GLF_DEEP"); return e ? e[0] != '0' : GLF_DEEP_DEFAULT; }();

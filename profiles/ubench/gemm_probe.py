@@ -36,7 +36,7 @@ for mode, M, N, K in SHAPES:
     else:
         sp = ops._tn_split(K, M, N, 1)
         run = lambda X=Ax, Y=Bx, pa=pa, pb=pb: ops.gemm("tn", X, Y, C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
-    if pa or pb:                                   # the pre-split path must reproduce the in-kernel split bit for bit
+    if (pa or pb) and not os.environ.get("PROBE_NOCHECK"):   # the pre-split path must reproduce the in-kernel split bit for bit
         run(A, B, False, False)
         ref = C.clone()
         run()
