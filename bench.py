@@ -66,11 +66,16 @@ def pmc_traffic_per_launch(kernel: str, precision: str):
     if not os.path.exists(path):
         path = os.path.join(ROOT, "profiles", f"r01_bench_c2_{precision}_pmc_hbm_traffic.csv")
     try:
+        launches, gb = 0, 0.0
         for line in open(path).read().splitlines()[1:]:
             name, rest = line.rsplit(",", 5)[0], line.rsplit(",", 5)[1:]
-            # profile names carry every template argument ("gemm_rows_f16s8_kernel<false, 3, false>"): match on the leading ones
-            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")):
-                return {"bytes_per_launch": float(rest[4]) * 1e6, "unit": "B", "source": os.path.relpath(path, ROOT)}
+            # profile names carry every template argument ("gemm_rows_f16s8_kernel<false, 3, false, true, ...>"): the family is
+            # every instantiation with the same leading arguments (plain / gather), whatever the operand forms
+            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and rest[0]:
+                launches += int(rest[0])
+                gb += float(rest[3])
+        if launches:
+            return {"bytes_per_launch": round(gb * 1e9 / launches), "unit": "B", "source": os.path.relpath(path, ROOT)}
     except (OSError, ValueError, IndexError):
         pass
     return None

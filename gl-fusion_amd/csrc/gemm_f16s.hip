@@ -1269,6 +1269,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     const float p_alpha = args.alpha * inv_a * inv_b;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+    unsigned long long wg_t0 = __builtin_amdgcn_s_memtime(), wg_t1 = 0, wg_t2 = 0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform, and known to be: everything derived from it stays in SGPRs
@@ -1519,10 +1522,16 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         __syncthreads();                                                                                      \
     }
     int it = 0;
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+    wg_t1 = __builtin_amdgcn_s_memtime();
+#endif
     for (; it + 3 < ntiles; ++it) GLF_T8_BODY(true, true, true)
     if (it + 2 < ntiles) { GLF_T8_BODY(true, false, true) ++it; }
     if (it + 1 < ntiles) { GLF_T8_BODY(false, false, true) ++it; }
     GLF_T8_BODY(false, false, false)
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+    wg_t2 = __builtin_amdgcn_s_memtime();
+#endif
 
     const bool atomic = !args.partial && ((p_split > 1) || p_accumulate);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
@@ -1547,6 +1556,16 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
         if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
     }
+#if defined(GLF_STAMPS) && GLF_STAMPS == 2
+    if (args.stamps != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && blockIdx.y == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long wg_t3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* d_ = args.stamps + 64 + wave * 4;
+            d_[0] = wg_t0; d_[1] = wg_t1; d_[2] = wg_t2; d_[3] = wg_t3; if (wave == 0) args.stamps[63] = (unsigned long long)ntiles;
+        }
+    }
+#endif
 }
 
 // max |x| over a [rows, cols] view (row stride ld) -> *out (non-negative floats order like their bit patterns)
@@ -1722,6 +1741,9 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
 int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
     GemmArgs a = a0;
     a.zeros = zero_page();
+#ifdef GLF_STAMPS
+    a.stamps = reinterpret_cast<unsigned long long*>(stamps_buffer());
+#endif
     const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
     const bool wide = a.M > BM;             // 256-wide tiles: re-derive the grid
     dim3 g2 = grid;

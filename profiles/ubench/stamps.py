@@ -26,19 +26,33 @@ ama, amb = ops.amax_of(A), ops.amax_of(B)
 pa, pb = "a" in pack, "b" in pack
 Ax = ops.packed_of(A, ama) if pa else A
 Bx = ops.packed_of(B, amb) if pb else B
+TN = os.environ.get("STAMPS_TN") == "1"            # the weight-gradient kernel instead: C[M][N] = A[K][M]^T B[K][N]
+if TN:
+    del A, B, Cm, Ax, Bx
+    M, N, K = 3072, 2048, 150528
+    A = torch.rand(K, M, device=dev, generator=g) * 2 - 1
+    B = torch.rand(K, N, device=dev, generator=g) * 2 - 1
+    Cm = torch.zeros(M, N, device=dev)
+    ama, amb = ops.amax_of(A), ops.amax_of(B)
+    Ax = ops.packed_of(A, ama) if pa else A
+    Bx = ops.packed_of(B, amb) if pb else B
+    sp = ops._tn_split(K, M, N, 1)
 for _ in range(40):                                # long enough for the clock to settle
-    ops.gemm("nt", Ax, Bx, Cm, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
+    if TN:
+        ops.gemm("tn", Ax, Bx, Cm, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
+    else:
+        ops.gemm("nt", Ax, Bx, Cm, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
 torch.cuda.synchronize()
 buf = np.zeros(1024, dtype=np.uint64)
 fn = lib.glf_debug_stamps
 fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
 assert fn(buf.ctypes.data) == 0
 if os.environ.get("STAMPS_MODE") == "2":            # workgroup-level stamps (library built with -DGLF_STAMPS=2)
-    w = buf[:32].reshape(8, 4).astype(np.int64)
-    t0 = w[:, 0].min()
-    print(f"== {prec} pack={pack or '-'}: one workgroup (K = {K}: {K // 32} iterations), shader cycles per wave: prologue | main loop (per iteration) | epilogue")
+    w = (buf[64:96] if TN else buf[:32]).reshape(8, 4).astype(np.int64)
+    nit = int(buf[63]) if TN else K // 32
+    print(f"== {prec} {'tn' if TN else 'nt'} pack={pack or '-'}: one workgroup ({nit} iterations), shader cycles per wave: prologue | main loop (per iteration) | epilogue")
     for i in range(8):
-        print(f"{i:4d} {w[i, 1] - w[i, 0]:8d} | {w[i, 2] - w[i, 1]:8d} ({(w[i, 2] - w[i, 1]) / (K // 32):7.1f}) | {w[i, 3] - w[i, 2]:8d}   total {w[i, 3] - w[i, 0]}")
+        print(f"{i:4d} {w[i, 1] - w[i, 0]:8d} | {w[i, 2] - w[i, 1]:8d} ({(w[i, 2] - w[i, 1]) / nit:7.1f}) | {w[i, 3] - w[i, 2]:8d}   total {w[i, 3] - w[i, 0]}")
     sys.exit(0)
 st = buf.reshape(8, 16, 8)[:, :, :5].astype(np.int64)
 print(f"== {prec} pack={pack or '-'}: per-wave iteration period and segment lengths (shader cycles), mean over 15 iterations")
