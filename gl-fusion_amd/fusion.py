@@ -25,7 +25,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
 from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
-                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, pick, zeros)
+                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, packed_hit, pick, zeros)
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
@@ -101,7 +101,7 @@ class TpaviFn(Function):
         xa, pa = pick(x, act_packed(x, am_x) if ok else None, ok)       # read again by the weight gradient of the projections
         gemm("nt", xa, wb, qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat, amax_a=am_x, amax_b=am_wc, amax_c=am_q,
              a_packed=pa, b_packed=pb)
-        ctx.x_packed = (xa, am_x) if pa else None
+        ctx.x_packed = (xa, am_x) if (pa and packed_hit(x, am_x) is not None) else None      # retained while memory allows
         ctx.qkv_owner = th_w                      # parameter the stacked operand (and its cached transpose) is keyed on
         set_amax(qkv, am_q)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
@@ -145,7 +145,7 @@ class TpaviFn(Function):
         am_y = amax_of(y)
         ya, pa = pick(y, act_packed(y, am_y) if ok else None, ok)
         gemm("nt", ya, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=am_y, amax_b=am_zw, a_packed=pa, b_packed=pb)
-        ctx.y_packed = (ya, am_y) if pa else None
+        ctx.y_packed = (ya, am_y) if (pa and packed_hit(y, am_y) is not None) else None
 
         mean = torch.empty(c, **f32)
         invstd = torch.empty(c, **f32)
@@ -196,7 +196,7 @@ class TpaviFn(Function):
         dzW = (zeros if tn_needs_zero(sp) else torch.empty)(c, ci, **f32)
         am_dwz, am_q = amax_of(dwz), amax_of(qkv)
         ok = tn_presplit_ok(c, ci, c, ci)
-        dwz_a, pa = pick(dwz, act_packed(dwz, am_dwz) if ok else None, ok)       # shared with the NT contraction below
+        dwz_a, pa = pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)       # shared with the NT contraction below
         am_y = ctx.y_packed[1] if ctx.y_packed is not None else amax_of(y)
         yb, pb = pick(y, ctx.y_packed[0] if ctx.y_packed is not None else None, ok)
         gemm("tn", dwz_a, yb, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=am_y, a_packed=pa, b_packed=pb)
@@ -209,7 +209,7 @@ class TpaviFn(Function):
             zWT, am_zw = weight_T(zW, wz_o), amax_of(wz_o)
             ok = nt_presplit_ok(c, c, c)
             wb, pb = pick(zWT, weight_packed(zWT, wz_o, "T2", am_zw), ok)
-            da, pa = pick(dwz, act_packed(dwz, am_dwz) if ok else None, ok)
+            da, pa = pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)
             gemm("nt", da, wb, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
                  amax_c=am_dy_slot, a_packed=pa, b_packed=pb)
             del da
@@ -270,7 +270,7 @@ class TpaviFn(Function):
         dWcat = (zeros if tn_needs_zero(sp) else torch.empty)(c3, c, **f32)
         am_dq = amax_of(dqkv)
         ok = tn_presplit_ok(c3, c, c3, c)
-        dq_a, pa = pick(dqkv, act_packed(dqkv, am_dq) if ok else None, ok)
+        dq_a, pa = pick(dqkv, act_packed(dqkv, am_dq, True) if ok else None, ok)
         am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
         xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
         gemm("tn", dq_a, xb, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=sp, amax_a=am_dq, amax_b=am_x, a_packed=pa, b_packed=pb)
@@ -283,7 +283,7 @@ class TpaviFn(Function):
             am_wc = amax_of(Wcat)
             ok = nt_presplit_ok(c3, c3, c3)
             wb, pb = pick(WcatT, weight_packed(WcatT, Wcat, "T2", am_wc), ok)
-            da, pa = pick(dqkv, act_packed(dqkv, am_dq) if ok else None, ok)
+            da, pa = pick(dqkv, act_packed(dqkv, am_dq, True) if ok else None, ok)
             gemm("nt", da, wb, dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True, amax_a=am_dq, amax_b=am_wc,
                  a_packed=pa, b_packed=pb)
         else:

@@ -6,6 +6,8 @@ from __future__ import annotations
 import copy
 from typing import Dict, Sequence
 
+import os
+
 import torch
 from torch import nn
 
@@ -14,6 +16,9 @@ from ..fusion import tpavi_forward
 from .layers import Conv2d, ReLU, conv_bn_act
 from .segmentation import deeplabv3_resnet50_iekd
 
+
+# the two fusion blocks on side streams of their own (GLF_FUSION_STREAMS=0: one after the other on the current stream)
+_FUSION_STREAMS = os.environ.get("GLF_FUSION_STREAMS", "1") != "0"
 
 class TPAVIModule(nn.Module):
     """ours.py:770-917.  Built modes: 'dot' (shipped) and 'embedded' (softmax); dimension=3,
@@ -152,9 +157,10 @@ class Global_and_Local(_PerViewNetworks):
         f4_glob = {v: s[1] for v, s in zip(views, secs)}
         f4_local = {v: s[2] for v, s in zip(views, secs)}
         # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
-        g_out, l_out = ops.parallel_sections([
+        fusion_jobs = [
             lambda: self._attend(self.global_attn, ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
-            lambda: self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))])
+            lambda: self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))]
+        g_out, l_out = ops.parallel_sections(fusion_jobs) if _FUSION_STREAMS else [j() for j in fusion_jobs]
         fused = self._fuse(g_out, l_out)                                                        # ours.py:1833-1834
 
         def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second

@@ -388,23 +388,62 @@ def packed_hit(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.
     return None
 
 
-def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+# A pre-split image kept from the forward pass to the backward pass is a second copy of that activation.  At C2 that is 33 GB
+# on top of 56 GB; at the 5-view 224^2 shape it took the step from 180 GB to 264 GB of the 288 GB and the allocator started
+# thrashing (1.16 s -> 4.0 s per step).  So images are RETAINED (on the tensor object, for the weight gradient) only while the
+# device has room: while the caching allocator has RESERVED less than this fraction of the device memory (reserved, not
+# allocated: with one block pool per stream the reserved figure runs far ahead -- at that shape 205 GB allocated already
+# thrashed).  Above it an image lives for the launches of one autograd node: 1.02 s per step there, against 1.12 s without
+# any pre-split.
+PRESPLIT_KEEP_FRAC = float(os.environ.get("GLF_PRESPLIT_KEEP_FRAC", "0.5"))
+PRESPLIT_OFF_FRAC = float(os.environ.get("GLF_PRESPLIT_OFF_FRAC", "0.6"))
+_dev_total = {}
+_retain_off = {}
+
+
+def retain_ok(dev) -> bool:
+    """Retained images sit in memory across the peak of the step (end of forward), so the decision cannot be made tensor by
+    tensor: once the allocator has been seen above PRESPLIT_OFF_FRAC of the device, retention is off for the rest of the
+    process (the workload does not fit with second copies; the first step pays for finding out)."""
+    tot = _dev_total.get(dev)
+    if tot is None:
+        tot = _dev_total[dev] = torch.cuda.get_device_properties(dev).total_memory
+    off = _retain_off.get(dev, 0)
+    if off:
+        if off == 1 and torch.cuda.memory_allocated(dev) < 0.3 * tot:
+            # first pack of a later step: the images retained before the switch are gone -- hand the pools they inflated
+            # back to the device once (a later step needs less than the one that found out)
+            torch.cuda.empty_cache()
+            _retain_off[dev] = 2
+        return False
+    r = torch.cuda.memory_reserved(dev)
+    if r > PRESPLIT_OFF_FRAC * tot:
+        _retain_off[dev] = 1
+        return False
+    return r < PRESPLIT_KEEP_FRAC * tot
+
+
+def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor], retain: Optional[bool] = None) -> Optional[torch.Tensor]:
     """packed_of(t) for an activation / gradient tensor, remembered on the tensor object (like its amax) so that every
     contraction that reads it -- a conv input in the forward of each consumer and again in its weight gradient, an output
-    gradient in dgrad and wgrad -- shares one split pass.  None when not applicable."""
+    gradient in dgrad and wgrad -- shares one split pass.  retain: keep the image alive with t (default: while the device
+    has memory to spare, see retain_ok; gradients pass True: they die with their autograd node).  None when not applicable."""
     if not presplit_ok(t, amax):
         return None
     pk = packed_hit(t, amax)
     if pk is not None:
         return pk
     pk = packed_of(t, amax)
-    try:
-        t._glf_packed = (t._version, t.data_ptr(), amax, pk)
-    except AttributeError:
-        pass
-    share = getattr(t, "_glf_pack_share", None)
-    if share is not None:
-        share[0] = (t.data_ptr(), amax, pk, torch.cuda.current_stream())
+    if retain is None:
+        retain = retain_ok(t.device)
+    if retain:
+        try:
+            t._glf_packed = (t._version, t.data_ptr(), amax, pk)
+        except AttributeError:
+            pass
+        share = getattr(t, "_glf_pack_share", None)
+        if share is not None:
+            share[0] = (t.data_ptr(), amax, pk, torch.cuda.current_stream())
     return pk
 
 
@@ -564,7 +603,7 @@ class Conv2dFn(Function):
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
              amax_a=am_x, amax_b=am_w, colstats=colstats, a_packed=pa, b_packed=pb)
         ctx.save_for_backward(x, wt)
-        ctx.x_packed = (xa, am_x) if pa else None      # the weight gradient reads the same image
+        ctx.x_packed = (xa, am_x) if (pa and packed_hit(x, am_x) is not None) else None      # retained: the weight gradient reads the same image
         ctx.join = getattr(x, "_glf_join", None) if plain else None
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
@@ -606,7 +645,7 @@ class Conv2dFn(Function):
                     wT = tap_major_T(ctx.weight_ref)
                     ok = nt_presplit_ok(cout, cout, cout)
                     ok_dy = ok and cin * bin(mask).count("1") >= PRESPLIT_MIN_COLS
-                    da, pa = pick(dy, act_packed(dy, am_dy) if ok_dy else None, ok_dy)
+                    da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
                     wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
                     gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                          taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
@@ -634,7 +673,7 @@ class Conv2dFn(Function):
             am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
             # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
             ok_dy = ok and (packed_hit(dy, am_dy) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
-            da, pa = pick(dy, act_packed(dy, am_dy) if ok_dy else None, ok_dy)
+            da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
             xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
             gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                  tap_stride_b=cout * cin, gather=0 if plain else 1,
@@ -743,7 +782,7 @@ class ConvCatFn(Function):
                 if split_mode() and cout % 32 == 0:
                     w2T = weight_T(w2, ctx.weight_ref)
                     ok = nt_presplit_ok(cout, cout, cout)
-                    da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                    da, pa = pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
                     wb, pb = pick(w2T, weight_packed(w2T, ctx.weight_ref, "T2", am_w) if ok else None, ok)
                     gemm("nt", da, wb, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
                          amax_a=am_dy, amax_b=am_w, amax_c=am_dc, a_packed=pa, b_packed=pb)
@@ -762,7 +801,7 @@ class ConvCatFn(Function):
                 if tn_needs_zero(split):
                     zero_(dw)
                 ok = tn_presplit_ok(cout, ctot, cout, ctot)
-                da, pa = pick(dy, act_packed(dy, am_dy) if ok else None, ok)
+                da, pa = pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
                 gemm("tn", da, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
                      amax_a=am_dy, amax_b=amax_of(t0), a_packed=pa)
             return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)

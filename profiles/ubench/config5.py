@@ -38,8 +38,13 @@ def step():
     return loss
 
 
-step()
-torch.cuda.synchronize()
+gb = 2 ** 30
+for i in range(3):                                  # untimed: the first steps size the allocator's pools (and decide whether pre-split
+    ts = time.perf_counter()                        # images can be retained for the backward pass, ops.retain_ok)
+    step()
+    torch.cuda.synchronize()
+    print(f"  warm-up step {i}: {(time.perf_counter() - ts) * 1e3:.0f} ms, allocated peak {torch.cuda.max_memory_allocated() / gb:.1f} GB, "
+          f"reserved {torch.cuda.memory_reserved() / gb:.1f} GB, retention off: {bool(ops._retain_off)}", flush=True)
 t0 = time.perf_counter()
 for _ in range(2):
     l = step()
