@@ -455,6 +455,37 @@ def test_presplit_operands_reproduce_in_kernel_split_bitwise(cfg, prec):
             assert err <= 1e-6 * a.abs().max().item(), f"{name}: pre-split differs from in-kernel split by {err:.3e}"
 
 
+def test_presplit_images_are_not_retained_when_memory_is_short():
+    """ops.retain_ok: once the allocator has reserved more than PRESPLIT_OFF_FRAC of the device, pre-split images are no
+    longer attached to the tensors they were made from (they live for one autograd node) -- and the results do not change."""
+    from glfusion_amd import ops as _ops
+    n, h, w, cin, cout = 2, 28, 28, 128, 1024
+    x = rnd(n, h, w, cin, seed=75).to(DEV)
+    wt = (rnd(cout, cin, 1, 1, seed=76) / np.sqrt(cin)).to(DEV)
+    gy = rnd(n, h, w, cout, seed=77).to(DEV)
+    keep = (_ops.PRESPLIT_OFF_FRAC, dict(_ops._retain_off))
+    outs = []
+    _ops.set_precision("f16x3")
+    try:
+        for frac in (keep[0], 0.0):
+            _ops.PRESPLIT_OFF_FRAC = frac
+            _ops._retain_off.clear()
+            xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+            y = _ops.conv2d(xd, wd, None, 1, 0, 1)
+            retained = getattr(xd, "_glf_packed", None) is not None
+            assert retained == (frac > 0.0), f"retention {retained} at OFF_FRAC {frac}"
+            y.backward(gy)
+            outs.append((y.detach().clone(), xd.grad.clone(), wd.grad.clone()))
+        assert _ops._retain_off, "the switch did not trip"
+    finally:
+        _ops.PRESPLIT_OFF_FRAC = keep[0]
+        _ops._retain_off.clear()
+        _ops._retain_off.update(keep[1])
+        _ops.set_precision("f32")
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        assert torch.equal(a, b), f"{name} changed with retention off: {(a - b).abs().max().item():.3e}"
+
+
 def test_split_f16_packed_layout_and_errors():
     """glf_split_f16_packed: every float4 becomes {h0..h3, l0..l3} with x * s = h + 2^-11 l; bad strides are refused."""
     from glfusion_amd import ops as _ops
