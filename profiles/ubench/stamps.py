@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of the split-fp16 NT contraction's main loop (diagnostic build: csrc compiled with -DGLF_STAMPS into
-lib/libglfusion_stamps.so, selected through GLF_LIB_PATH).  One workgroup in the middle of the grid records s_memtime at five
+"""In-kernel timeline of the split-fp16 NT contraction's main loop (diagnostic builds: `make -C gl-fusion_amd/csrc stamps`
+compiles csrc with -DGLF_STAMPS=1 / =2 into lib/libglfusion_stamps.so / libglfusion_stamps2.so, selected through GLF_LIB_PATH;
+STAMPS_MODE=2 reads the per-workgroup stamps of the second one, STAMPS_TN=1 times the weight-gradient kernel instead).  One workgroup in the middle of the grid records s_memtime at five
 points of 16 consecutive iterations per wave: S0 top, S1 after the first 6 MFMAs were issued, S2 after 12, S3 after 18,
 S4 after 24 (before the barrier).  Usage: GLF_LIB_PATH=.../libglfusion_stamps.so stamps.py [precision] [pack]"""
 import ctypes
