@@ -340,6 +340,8 @@ PRESPLIT = os.environ.get("GLF_PRESPLIT", "1") != "0"
 # weight-gradient kernel ~15 % of a time proportional to rows x K x (output columns x taps).  Break-even measured near
 # columns x taps = 1000.  (Weights are always pre-split: once per update, cached.)
 PRESPLIT_MIN_COLS = int(os.environ.get("GLF_PRESPLIT_MIN_COLS", "1024"))
+WGRAD_STREAM = os.environ.get("GLF_WGRAD_STREAM", "0") != "0"      # a conv's weight gradient on a side stream of its dgrad
+_wgrad_streams = {}
 _packed_cache = {}
 
 
@@ -619,71 +621,100 @@ class Conv2dFn(Function):
         rows_o = n * ho * wo
         dx = dw = db = None
         am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
-        if ctx.needs_input_grad[0]:
-            mask = 1 if plain else tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
-            if mask == 0:
-                dx = zeros(x.shape, device=x.device)
-            else:
-                frac = 1.0 if plain or stride != 1 else rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask)
-                if not plain and bin(mask).count("1") > 1 and region_mode(taps, kh, stride, pad, dil, ho, wo, h, w, cout, frac):
-                    rect = 2
+        def dgrad():
+            dx = None
+            if True:
+                mask = 1 if plain else tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
+                if mask == 0:
+                    dx = zeros(x.shape, device=x.device)
                 else:
-                    rect = int(not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1 and frac < _rect_thr("dgrad"))
-                parked = None
-                if ctx.join is not None:              # the shortcut's gradient is waiting: add this dgrad onto it in the epilogue
-                    parked, ctx.join.parked = ctx.join.parked, None
-                    if parked is None:
-                        raise RuntimeError("glfusion_amd: gradient join reached before the shortcut's gradient was produced")
-                acc = parked is not None
-                if acc:
-                    dx = parked
-                else:
-                    dx = zeros(x.shape, device=x.device) if rect == 1 else torch.empty_like(x)
-                if split_mode() and cout % 32 == 0:
-                    # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
-                    am_dx = amax_slot(dx.device) if acc else None
-                    wT = tap_major_T(ctx.weight_ref)
-                    ok = nt_presplit_ok(cout, cout, cout)
-                    ok_dy = ok and cin * bin(mask).count("1") >= PRESPLIT_MIN_COLS
-                    da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
-                    wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
-                    gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
-                         taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
-                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect,
-                         amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx, a_packed=pa, b_packed=pb)
+                    frac = 1.0 if plain or stride != 1 else rect_fraction(2, h, w, ho, wo, kh, kw, pad, dil, mask)
+                    if not plain and bin(mask).count("1") > 1 and region_mode(taps, kh, stride, pad, dil, ho, wo, h, w, cout, frac):
+                        rect = 2
+                    else:
+                        rect = int(not plain and taps > 1 and stride == 1 and bin(mask).count("1") > 1 and frac < _rect_thr("dgrad"))
+                    parked = None
+                    if ctx.join is not None:              # the shortcut's gradient is waiting: add this dgrad onto it in the epilogue
+                        parked, ctx.join.parked = ctx.join.parked, None
+                        if parked is None:
+                            raise RuntimeError("glfusion_amd: gradient join reached before the shortcut's gradient was produced")
+                    acc = parked is not None
                     if acc:
-                        dx._glf_amax = None
-                        set_amax(dx, am_dx)            # the maximum of the SUM, from the accumulating epilogue
+                        dx = parked
+                    else:
+                        dx = zeros(x.shape, device=x.device) if rect == 1 else torch.empty_like(x)
+                    if split_mode() and cout % 32 == 0:
+                        # dgrad as NT on the split-bf16 kernels: B_tap[n = ci][k = co]
+                        am_dx = amax_slot(dx.device) if acc else None
+                        wT = tap_major_T(ctx.weight_ref)
+                        ok = nt_presplit_ok(cout, cout, cout)
+                        ok_dy = ok and cin * bin(mask).count("1") >= PRESPLIT_MIN_COLS
+                        da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
+                        wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
+                        gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
+                             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
+                             geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect,
+                             amax_a=am_dy, amax_b=am_w, accumulate=acc, amax_c=am_dx, a_packed=pa, b_packed=pb)
+                        if acc:
+                            dx._glf_amax = None
+                            set_amax(dx, am_dx)            # the maximum of the SUM, from the accumulating epilogue
+                    else:
+                        gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+                             tap_stride_b=cout * cin, gather=0 if plain else 2,
+                             geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect, accumulate=acc)
+                        if acc:
+                            dx._glf_amax = None
+            return dx
+
+        def wgrad():
+            dw = None
+            if ctx.needs_input_grad[1]:
+                mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+                ntap = bin(mask).count("1")
+                rect = (not plain and taps > 1 and stride == 1 and ntap > 1
+                        and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("wgrad"))
+                frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
+                split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
+                full = mask == (1 << taps) - 1
+                dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
+                ok = tn_presplit_ok(cout, cin, cout, cin)
+                am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
+                # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
+                ok_dy = ok and (packed_hit(dy, am_dy) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
+                da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
+                xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
+                gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
+                     tap_stride_b=cout * cin, gather=0 if plain else 1,
+                     geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,
+                     amax_a=am_dy, amax_b=am_x, a_packed=pa, b_packed=pb)
+                if taps == 1:
+                    dw = dwt.view(wshape)
                 else:
-                    gemm("nn", dy, wt, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
-                         tap_stride_b=cout * cin, gather=0 if plain else 2,
-                         geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect, accumulate=acc)
-                    if acc:
-                        dx._glf_amax = None
-        if ctx.needs_input_grad[1]:
-            mask = 1 if plain else tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
-            ntap = bin(mask).count("1")
-            rect = (not plain and taps > 1 and stride == 1 and ntap > 1
-                    and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("wgrad"))
-            frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
-            split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
-            full = mask == (1 << taps) - 1
-            dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
-            ok = tn_presplit_ok(cout, cin, cout, cin)
-            am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
-            # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
-            ok_dy = ok and (packed_hit(dy, am_dy) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
-            da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
-            xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
-            gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
-                 tap_stride_b=cout * cin, gather=0 if plain else 1,
-                 geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect,
-                 amax_a=am_dy, amax_b=am_x, a_packed=pa, b_packed=pb)
-            if taps == 1:
-                dw = dwt.view(wshape)
-            else:
-                dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
-                check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+                    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+                    check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+            return dw
+
+        if WGRAD_STREAM and STREAMS and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # dgrad and wgrad of one conv are independent and read the same dy: the weight gradient goes to a side stream of
+            # the stream this node runs on (its workgroups fill the partial last round of the dgrad kernel and vice versa)
+            if presplit_ok(dy, am_dy) and (cin * taps >= PRESPLIT_MIN_COLS):
+                act_packed(dy, am_dy, True)                  # the shared image is made before the fork, on this stream
+            cur = torch.cuda.current_stream()
+            side = _wgrad_streams.get(cur.cuda_stream)
+            if side is None:
+                side = _wgrad_streams[cur.cuda_stream] = torch.cuda.Stream(device=dy.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dw = wgrad()
+            dx = dgrad()
+            cur.wait_stream(side)
+            if dw is not None:
+                dw.record_stream(cur)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = dgrad()
+            if ctx.needs_input_grad[1]:
+                dw = wgrad()
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, rows_o, cout)
         return dx, dw, db, None, None, None, None
