@@ -241,6 +241,30 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
         }
     }
+    // Fast gather form (forward / wgrad-style gathers, and dgrad gathers of stride-1 convs -- everything but the dgrad of a
+    // strided conv): a row keeps (rb, y0, x0) = its source pixel index and coordinates for tap offset (0, 0); a tap then is
+    // one uniform offset pair (oy, ox): source = rb + oy * ws + ox, in range iff 0 <= y0 + oy < hs and 0 <= x0 + ox < ws.  The
+    // general map_src() (an integer division per call, two more for a strided dgrad, divergent branches around each) cost
+    // ~3.7 k cycles per tap change and ~20 k in the tap census below: 29 % of a 256 -> 256 3x3 conv's workgroup time
+    // (in-kernel stamps: prologue 26 k, 2 333 cycles per iteration against 1 869 for a plain GEMM).
+    const bool fastg = GATHER && (p_gather == 1 || g_stride == 1);
+    if (fastg) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (a_n[j] >= 0) {
+                const int y0 = (p_gather == 1) ? a_y[j] * g_stride - g_pad : a_y[j] + g_pad;
+                const int x0 = (p_gather == 1) ? a_x[j] * g_stride - g_pad : a_x[j] + g_pad;
+                a_n[j] = (a_n[j] * g_hs + y0) * g_ws + x0; a_y[j] = y0; a_x[j] = x0;
+            } else { a_n[j] = 0; a_y[j] = -(1 << 30); a_x[j] = 0; }          // never in range
+        }
+    }
+    // tap -> its uniform offsets (oy, ox) in source pixels
+    auto tap_offsets = [&](int t, int& oy, int& ox) __attribute__((always_inline)) {
+        int ky = 0, kx = __builtin_amdgcn_readfirstlane(t);
+        while (kx >= g_kw) { kx -= g_kw; ++ky; }
+        oy = (p_gather == 1 ? ky : -ky) * g_dil;
+        ox = (p_gather == 1 ? kx : -kx) * g_dil;
+    };
     if (GATHER && p_taps > 1 && !p_rect) {
         if (tid == 0) *s_mask = 0u;
         __syncthreads();
@@ -248,9 +272,17 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             unsigned local = 0;
             for (unsigned mm = mask; mm; mm &= mm - 1) {
                 const int t = __ffs(mm) - 1;
+                if (fastg) {
+                    int oy, ox;
+                    tap_offsets(t, oy, ox);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (a_n[j] >= 0 && map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
+                    for (int j = 0; j < 4; ++j)
+                        if ((unsigned)(a_y[j] + oy) < (unsigned)g_hs && (unsigned)(a_x[j] + ox) < (unsigned)g_ws) local |= 1u << t;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (a_n[j] >= 0 && map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], t) >= 0) local |= 1u << t;
+                }
             }
             if (local) atomicOr(s_mask, local);
         }
@@ -282,16 +314,27 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             kc = 0;
             tap = __ffs(rem_mask) - 1;
             rem_mask &= rem_mask - 1;
+            if (fastg) {
+                int oy, ox;
+                tap_offsets(tap, oy, ox);
+                const int d = oy * g_ws + ox;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                long long off;
-                if (GATHER) {
-                    const int sr = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
-                    off = (sr >= 0) ? (long long)sr * p_lda : -1;
-                } else {
-                    off = a_off[j];
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (unsigned)(a_y[j] + oy) < (unsigned)g_hs && (unsigned)(a_x[j] + ox) < (unsigned)g_ws;
+                    pa[j] = (ok ? A + (long long)(a_n[j] + d) * p_lda : p_zero) + 4 * ac;          // padding rows read the zero page
                 }
-                pa[j] = (off >= 0 ? A + off : p_zero) + 4 * ac;          // padding / overhang rows read the zero page
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    long long off;
+                    if (GATHER) {
+                        const int sr = (a_n[j] >= 0) ? map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, p_gather, a_n[j], a_y[j], a_x[j], tap) : -1;
+                        off = (sr >= 0) ? (long long)sr * p_lda : -1;
+                    } else {
+                        off = a_off[j];
+                    }
+                    pa[j] = (off >= 0 ? A + off : p_zero) + 4 * ac;          // padding / overhang rows read the zero page
+                }
             }
             const float* Bt = B + (long long)tap * p_tsb;
 #pragma unroll
@@ -1099,6 +1142,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
         for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
         tap = __ffs(mm) - 1;
     }
+    int tap_cy = 0, tap_cx = 0;  // gathered B rows: source pixel = (y * stride + tap_cy, x * stride + tap_cx)
+    if (GATHER) {
+        int ky = 0, kx = tap;
+        while (kx >= args.g.kw) { kx -= args.g.kw; ++ky; }
+        tap_cy = ky * args.g.dil - args.g.pad; tap_cx = kx * args.g.dil - args.g.pad;
+    }
     const int bz = blockIdx.z / p_split, sl = blockIdx.z - bz * p_split;
     const float* __restrict__ A = p_A + (long long)bz * p_bsa;
     const float* __restrict__ B = p_B + (long long)bz * p_bsb;
@@ -1144,7 +1193,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
                 const int yy = rem / r_w;
                 const int y = r_y0 + yy, x = r_x0 + rem - yy * r_w;
                 arow[j] = ((long long)n * g_hd + y) * g_wd + x;
-                if (r < r1) src[j] = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, n, y, x, tap);
+                if (r < r1) {          // (the tap is fixed for the workgroup: constant source offsets, no division for it)
+                    const int sy = y * g_stride + tap_cy, sx = x * g_stride + tap_cx;
+                    if ((unsigned)sy < (unsigned)g_hs && (unsigned)sx < (unsigned)g_ws) src[j] = (n * g_hs + sy) * g_ws + sx;
+                }
             } else if (r < r1) {
                 src[j] = r;
             }
@@ -1347,6 +1399,12 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     }
     const float* pa[4];          // row bases (uniform); the lane's column offset a_col is added at the load
     const float* pb[2];
+    int tap_cy = 0, tap_cx = 0;  // gathered B rows: source pixel = (y * stride + tap_cy, x * stride + tap_cx)
+    if (GATHER) {
+        int ky = 0, kx = tap;
+        while (kx >= g_kw) { kx -= g_kw; ++ky; }
+        tap_cy = ky * g_dil - g_pad; tap_cx = kx * g_dil - g_pad;
+    }
     // pointers of the NEXT tile to load, then step every row by 32
     auto advance = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1367,9 +1425,10 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
             long long src = br[j];
             bool ok = br[j] < r1 && b_col_ok;
             if (GATHER) {
-                const int sr = map_src(g_hs, g_ws, g_kw, g_stride, g_pad, g_dil, 1, bn[j], r_y0 + by[j], r_x0 + bx[j], tap);
-                ok = ok && sr >= 0;
-                src = sr;
+                // (the tap is fixed for the workgroup: its source offsets are two constants -- no per-row division, see map_src)
+                const int sy = (r_y0 + by[j]) * g_stride + tap_cy, sx = (r_x0 + bx[j]) * g_stride + tap_cx;
+                ok = ok && (unsigned)sy < (unsigned)g_hs && (unsigned)sx < (unsigned)g_ws;
+                src = (bn[j] * g_hs + sy) * g_ws + sx;
             }
             pb[j] = ok ? Bc + src * p_ldb : zb;
             br[j] += BK;

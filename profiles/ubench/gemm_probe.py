@@ -18,6 +18,29 @@ rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
 
 SHAPES = [("nt", 150528, 3072, 2048), ("nt", 150528, 2048, 1024), ("nt", 50176, 2048, 512), ("nt", 50176, 512, 2048),
           ("nt", 50176, 256, 1024), ("nt", 50176, 1024, 256), ("tn", 3072, 2048, 150528), ("tn", 2048, 512, 50176)]
+CONVS = [(64, 28, 256, 256, 1), (64, 28, 512, 512, 2), (64, 28, 2048, 256, 12), (64, 28, 256, 256, 2), (64, 55, 64, 64, 1), (64, 28, 128, 128, 1)]
+if os.environ.get("PROBE_CONV"):                  # 3x3 convs through the autograd op instead: forward, dgrad + wgrad (ms each side)
+    import torch.nn.functional as F
+    for nimg, hh, cin, cout, dil in CONVS:
+        x = rnd(nimg, hh, hh, cin).requires_grad_(True)
+        w = (rnd(cout, cin, 3, 3) / (3 * cin ** 0.5)).requires_grad_(True)
+        gy = rnd(nimg, hh, hh, cout)
+        def fwd():
+            return ops.conv2d(x, w, None, 1, dil, dil)
+        y = fwd(); y.backward(gy); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = fwd()
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = fwd(); y.backward(gy); x.grad = None; w.grad = None
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / reps - tf
+        fl = 2.0 * nimg * hh * hh * cin * cout * 9
+        print(f"{prec} conv3x3 {nimg}x{hh}x{hh} {cin}->{cout} dil {dil}: fwd {tf * 1e3:.3f} ms ({fl / tf / 1e12:.0f} TF dense), bwd {tb * 1e3:.3f} ms ({2 * fl / tb / 1e12:.0f} TF dense)", flush=True)
+    sys.exit(0)
 PACK = os.environ.get("PROBE_PACK", "")            # e.g. "ab": which operands go in pre-split
 LDPAD = int(os.environ.get("PROBE_LDPAD", "0"))    # NT shapes: row stride K + LDPAD floats (is a power-of-two stride a problem?)
 if os.environ.get("PROBE_SHAPES"):

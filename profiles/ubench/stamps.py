@@ -27,6 +27,20 @@ ama, amb = ops.amax_of(A), ops.amax_of(B)
 pa, pb = "a" in pack, "b" in pack
 Ax = ops.packed_of(A, ama) if pa else A
 Bx = ops.packed_of(B, amb) if pb else B
+CONV = os.environ.get("STAMPS_CONV")               # "cin,cout,dil": a 3x3 conv forward on 64 x 28 x 28 (the gathered NT kernel)
+if CONV:
+    cin, cout, dil = (int(v) for v in CONV.split(","))
+    del A, B, Cm, Ax, Bx
+    nimg, hh = 64, 28
+    M, N, K = nimg * hh * hh, cout, cin
+    A = torch.rand(M, cin, device=dev, generator=g) * 2 - 1
+    B = torch.rand(9, cout, cin, device=dev, generator=g) * 2 - 1
+    Cm = torch.empty(M, cout, device=dev)
+    ama, amb = ops.amax_of(A), ops.amax_of(B)
+    Ax = ops.packed_of(A, ama) if pa else A
+    Bx = ops.packed_of(B, amb) if pb else B
+    geo = (nimg, hh, hh, hh, hh, 3, 3, 1, dil, dil)
+    mask = ops.tap_mask(1, hh, hh, hh, hh, 3, 3, 1, dil, dil)
 TN = os.environ.get("STAMPS_TN") == "1"            # the weight-gradient kernel instead: C[M][N] = A[K][M]^T B[K][N]
 if TN:
     del A, B, Cm, Ax, Bx
@@ -39,7 +53,10 @@ if TN:
     Bx = ops.packed_of(B, amb) if pb else B
     sp = ops._tn_split(K, M, N, 1)
 for _ in range(40):                                # long enough for the clock to settle
-    if TN:
+    if CONV:
+        ops.gemm("nt", Ax, Bx, Cm, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, taps=9, mask=mask, tap_stride_b=N * K, gather=1, geo=geo,
+                 amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
+    elif TN:
         ops.gemm("tn", Ax, Bx, Cm, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split=sp, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
     else:
         ops.gemm("nt", Ax, Bx, Cm, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, amax_a=ama, amax_b=amb, a_packed=pa, b_packed=pb)
@@ -50,7 +67,7 @@ fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
 assert fn(buf.ctypes.data) == 0
 if os.environ.get("STAMPS_MODE") == "2":            # workgroup-level stamps (library built with -DGLF_STAMPS=2)
     w = (buf[64:96] if TN else buf[:32]).reshape(8, 4).astype(np.int64)
-    nit = int(buf[63]) if TN else K // 32
+    nit = int(buf[63]) if TN else (K // 32) * (bin(mask).count("1") if CONV else 1)
     print(f"== {prec} {'tn' if TN else 'nt'} pack={pack or '-'}: one workgroup ({nit} iterations), shader cycles per wave: prologue | main loop (per iteration) | epilogue")
     for i in range(8):
         print(f"{i:4d} {w[i, 1] - w[i, 0]:8d} | {w[i, 2] - w[i, 1]:8d} ({(w[i, 2] - w[i, 1]) / nit:7.1f}) | {w[i, 3] - w[i, 2]:8d}   total {w[i, 3] - w[i, 0]}")
