@@ -225,20 +225,31 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 
     int a_n[4], a_y[4], a_x[4];
     long long a_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = tm * BM8 + ar + 64 * j;
+    {
+        // pixel coordinates of the thread's first row by division, of the other three (64 rows further each) by carrying
+        int cn = 0, cy = 0, cx = 0;
         if (GATHER) {
-            if (m < pMe) {
-                const int hw = r_h * r_w;
-                const int n = m / hw, rem = m - n * hw;
-                const int yy = rem / r_w;
-                a_n[j] = n; a_y[j] = r_y0 + yy; a_x[j] = r_x0 + rem - yy * r_w;
-            } else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
-            a_off[j] = -1;
-        } else {
-            a_n[j] = 0; a_y[j] = 0; a_x[j] = 0;
-            a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
+            const int m0 = tm * BM8 + ar, hw = r_h * r_w;
+            cn = m0 / hw;
+            const int rem = m0 - cn * hw;
+            cy = rem / r_w; cx = rem - cy * r_w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = tm * BM8 + ar + 64 * j;
+            if (GATHER) {
+                if (m < pMe) { a_n[j] = cn; a_y[j] = r_y0 + cy; a_x[j] = r_x0 + cx; }
+                else { a_n[j] = -1; a_y[j] = 0; a_x[j] = 0; }
+                a_off[j] = -1;
+                if (j < 3 && m + 64 < pMe) {
+                    cx += 64;
+                    while (cx >= r_w) { cx -= r_w; ++cy; }
+                    while (cy >= r_h) { cy -= r_h; ++cn; }
+                }
+            } else {
+                a_n[j] = 0; a_y[j] = 0; a_x[j] = 0;
+                a_off[j] = (m < pM) ? (long long)m * p_lda : -1;
+            }
         }
     }
     // Fast gather form (forward / wgrad-style gathers, and dgrad gathers of stride-1 convs -- everything but the dgrad of a
@@ -265,7 +276,9 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         oy = (p_gather == 1 ? ky : -ky) * g_dil;
         ox = (p_gather == 1 ? kx : -kx) * g_dil;
     };
-    if (GATHER && p_taps > 1 && !p_rect) {
+    // tap census: drop the taps that fall into the padding for EVERY row of this tile.  It can only find one when the tile
+    // covers fewer than dil + 1 full image rows (otherwise each tap has a row it reaches): skipped for the small dilations.
+    if (GATHER && p_taps > 1 && !p_rect && BM8 < g_wd * (g_dil + 1)) {
         if (tid == 0) *s_mask = 0u;
         __syncthreads();
         if (ac == 0) {
