@@ -1193,6 +1193,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     float4 ra[4], rb[4];
     int rvalid[4];
 
+    // pixel coordinates (inside the tap's rectangle) of this thread's four rows of the NEXT tile to load: set once by
+    // division, advanced by 32 rows per tile by carrying (tiles are loaded in order)
+    int gn[4] = {0, 0, 0, 0}, gy[4] = {0, 0, 0, 0}, gx[4] = {0, 0, 0, 0};
+    if (GATHER) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + rr + 8 * j;
+            gn[j] = r / hw;
+            const int rem = r - gn[j] * hw;
+            gy[j] = rem / r_w; gx[j] = rem - gy[j] * r_w;
+        }
+    }
     auto load_tile = [&](int rbase) __attribute__((always_inline)) {
         long long src[4], arow[4];
 #pragma unroll
@@ -1201,15 +1213,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
             src[j] = -1;
             arow[j] = min(r, r1 - 1);
             if (GATHER) {
-                const int rc = min(r, r1 - 1);
-                const int n = rc / hw, rem = rc - n * hw;
-                const int yy = rem / r_w;
-                const int y = r_y0 + yy, x = r_x0 + rem - yy * r_w;
-                arow[j] = ((long long)n * g_hd + y) * g_wd + x;
                 if (r < r1) {          // (the tap is fixed for the workgroup: constant source offsets, no division for it)
+                    const int y = r_y0 + gy[j], x = r_x0 + gx[j];
+                    arow[j] = ((long long)gn[j] * g_hd + y) * g_wd + x;
                     const int sy = y * g_stride + tap_cy, sx = x * g_stride + tap_cx;
-                    if ((unsigned)sy < (unsigned)g_hs && (unsigned)sx < (unsigned)g_ws) src[j] = (n * g_hs + sy) * g_ws + sx;
+                    if ((unsigned)sy < (unsigned)g_hs && (unsigned)sx < (unsigned)g_ws) src[j] = (gn[j] * g_hs + sy) * g_ws + sx;
                 }
+                gx[j] += BK;
+                while (gx[j] >= r_w) { gx[j] -= r_w; ++gy[j]; }
+                while (gy[j] >= r_h) { gy[j] -= r_h; ++gn[j]; }
             } else if (r < r1) {
                 src[j] = r;
             }
