@@ -1009,17 +1009,25 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = p_bias[col + j];
             }
+            // region / rectangle stores: pixel coordinates of the lane's first row by division, of the next ones (4 rows on) by carrying
+            int en = 0, ey = 0, ex = 0;
+            if (p_rect) {
+                const int row0 = tm * BM8 + wm + r0, hw = r_h * r_w;
+                en = row0 / hw;
+                const int rem = row0 - en * hw;
+                ey = rem / r_w; ex = rem - ey * r_w;
+            }
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
                 const int rin = r0 + 4 * i;
                 const int row = tm * BM8 + wm + rin;
-                if (row >= pMe) continue;
+                if (row >= pMe) break;
                 long long orow = row;
                 if (p_rect) {
-                    const int hw = r_h * r_w;
-                    const int n = row / hw, rem = row - n * hw;
-                    const int yy = rem / r_w;
-                    orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+                    orow = ((long long)en * g_hd + r_y0 + ey) * g_wd + r_x0 + ex;
+                    ex += 4;
+                    while (ex >= r_w) { ex -= r_w; ++ey; }
+                    while (ey >= r_h) { ey -= r_h; ++en; }
                 }
                 const float4 a = *reinterpret_cast<const float4*>(tile + rin * 64 + c4);
                 float* dst = C + orow * p_ldc + col;
