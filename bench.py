@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -229,9 +230,21 @@ def main():
         HIP event pair around every contraction launch (on side streams a launch's event interval would include the time
         it shared the chip with other streams' kernels)."""
         ops.set_precision(precision)
+        if os.environ.get("GLF_BENCH_STEPTIMES", "0") != "0":       # diagnostic: every step fenced and timed (allocator / cache warm-up effects)
+            for i in range(args.warmup + args.steps):
+                ts = time.perf_counter()
+                step()
+                fence()
+                print(f"[bench] {precision} step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms, reserved "
+                      f"{torch.cuda.memory_reserved() / 2 ** 30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GB, "
+                      f"retention off: {dict(ops._retain_off)}", file=sys.stderr, flush=True)
         for _ in range(args.warmup):
             step()
         fence()
+        # Python's cyclic collector is kept out of the timed region (a generation-2 pass over the model's ~10^5 objects stalls
+        # the launch thread for tens of ms at a random step); it runs between the legs instead.  No step work is skipped.
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         host = 0.0
         for _ in range(args.steps):
@@ -240,6 +253,7 @@ def main():
             host += time.perf_counter() - th          # time the host spent enqueueing (step() does not synchronise)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
+        gc.enable()
         loss_val = float(loss)
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
