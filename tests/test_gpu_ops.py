@@ -396,6 +396,7 @@ REAL_CONVS = [
     (8, 28, 28, 2048, 256, 3, 36, 36),     # ASPP rate 36: centre tap only
     (8, 28, 28, 512, 512, 3, 4, 4),        # layer4 conv2
     (192, 28, 28, 1024, 2048, 1, 0, 1),    # W_z of the fusion block at C2: M = 64 frames x 3 views x 784 = 150 528 rows
+    (8, 28, 28, 160, 260, 3, 2, 2),        # ragged tiles in every kernel: 260 = 256 + 4 output channels, 160 input channels
 ]
 
 
@@ -421,7 +422,9 @@ def test_conv2d_real_shapes_fwd_dgrad_wgrad(ops, cfg):
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])
 @pytest.mark.parametrize("cfg", [(3, 28, 28, 64, 96, 1, 1, 0, 1, True), (2, 28, 28, 128, 64, 3, 1, 2, 2, True), (2, 28, 28, 256, 32, 3, 1, 24, 24, False),
                                  (2, 56, 56, 32, 64, 3, 2, 1, 1, True), (2, 28, 28, 512, 64, 3, 1, 12, 12, False),
-                                 (4, 28, 28, 256, 512, 1, 1, 0, 1, True)])
+                                 (4, 28, 28, 256, 512, 1, 1, 0, 1, True),
+                                 # ragged tiles: 260 output channels (a 256-wide wgrad tile + a 4-column overhang), 160 input channels
+                                 (2, 28, 28, 160, 260, 1, 1, 0, 1, True), (2, 28, 28, 160, 260, 3, 1, 2, 2, True)])
 def test_presplit_operands_reproduce_in_kernel_split_bitwise(cfg, prec):
     """Operands handed over in the packed pre-split image (glf_split_f16_packed; A and B of the NT kernels, A and B of the
     TN kernels, plain / gathered / per-tap rectangles / regions) must give the SAME BITS as the same call splitting in its
