@@ -94,7 +94,18 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(frames_per_view: int = 4, steps: int = 2):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(frames_per_view: int = 8, steps: int = 3):
     """The oracle's forward+backward on the host cores, same shapes per frame, a bounded sample."""
     from oracle import glfusion_ref as orc
     torch.manual_seed(0)
@@ -116,7 +127,7 @@ def cpu_baseline(frames_per_view: int = 4, steps: int = 2):
         orc.train_step(model, imgs, tgts)
     dt = (time.perf_counter() - t0) / steps
     clips = frames_per_view / T                           # 1 clip = V views x T frames
-    return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+    return {"value": clips / dt, "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"oracle (PyTorch-CPU fp32 restatement) fwd+bwd, 3 views x {frames_per_view} frames x 112x112, "
                       f"{steps} timed step(s) after 1 warm-up, {dt:.2f} s/step, scaled per frame to a 16-frame clip"}
 
@@ -157,6 +168,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the fp16-arithmetic leg (BASELINE.json configs[2])")
+    ap.add_argument("--no-graph", action="store_true", help="time the eagerly issued step instead of its hipGraph replay")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -189,6 +201,8 @@ def main():
 
     from glfusion_amd import ops
     from glfusion_amd.ddp import GradAllReducer
+    from glfusion_amd.engine import StepGraph
+    use_graph = not args.no_graph and os.environ.get("GLF_BENCH_GRAPH", "1") != "0"
 
     n_frames = args.clips * T
     model = build_model(dev)
@@ -201,15 +215,27 @@ def main():
         dist.all_reduce(one)                       # how many ranks the collective backend really joined
         ranks_seen = int(one.item())
 
-    def step():
-        for p in model.parameters():
-            p.grad = None
+    params = [p for p in model.parameters()]
+
+    def step_core():
+        """forward -> sum_v BCE(sum) -> backward (gradients land in p.grad)."""
         pred = model(imgs)[0]
         loss = None
         for v in VIEWS:
             l = ops.bce_with_logits_sum(pred[v], tgts[v])
             loss = l if loss is None else loss + l
         loss.backward()
+        return loss.detach()
+
+    def step():
+        """The eager step.  It pays the per-update weight work a real training step pays after every optimizer step: the
+        parameters are marked changed (every cache keyed on their version counter goes stale) and all weight-derived images
+        (tap-major / transposed layouts, maxima, pre-split fp16 images) are rebuilt by the multi-tensor refresh."""
+        torch.autograd.graph.increment_version(params)
+        ops.refresh_weights()
+        for p in params:
+            p.grad = None
+        loss = step_core()
         reducer.finalize()
         return loss
 
@@ -238,8 +264,17 @@ def main():
                 print(f"[bench] {precision} step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms, reserved "
                       f"{torch.cuda.memory_reserved() / 2 ** 30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GB, "
                       f"retention off: {dict(ops._retain_off)}", file=sys.stderr, flush=True)
+        # The timed step: by default ONE hipGraph launch per step (engine.StepGraph: advance the dropout counter, rebuild the
+        # weight-derived images, forward, loss, backward -- every kernel of the eager step, recorded once); --no-graph times
+        # the eager step, whose ~3 200 Python-issued launches make the host the bottleneck.
+        sg = None
+        if use_graph:
+            sg = StepGraph(step_core, params, warmup=2, reducer=reducer if world > 1 else None)
+            run = sg.replay
+        else:
+            run = step
         for _ in range(args.warmup):
-            step()
+            run()
         fence()
         # Python's cyclic collector is kept out of the timed region (a generation-2 pass over the model's ~10^5 objects stalls
         # the launch thread for tens of ms at a random step); it runs between the legs instead.  No step work is skipped.
@@ -247,16 +282,35 @@ def main():
         gc.disable()
         t0 = time.perf_counter()
         host = 0.0
+        host_first = None
         for _ in range(args.steps):
             th = time.perf_counter()
-            loss = step()
-            host += time.perf_counter() - th          # time the host spent enqueueing (step() does not synchronise)
+            loss = run()
+            host += time.perf_counter() - th          # time the host spent enqueueing (the step does not synchronise)
+            if host_first is None:
+                host_first = host                     # the queue was idle (fence above): enqueue cost without back-pressure
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         gc.enable()
         loss_val = float(loss)
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
+        eager_ms = None
+        if sg is not None:
+            sg.release()
+            sg = None
+            for p in params:
+                p.grad = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            # the same step issued eagerly from Python, for comparison (outside the metric): 1 untimed + 3 timed steps
+            step()
+            fence()
+            te = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            eager_ms = (time.perf_counter() - te) / 3 * 1e3
         if os.environ.get("GLF_BENCH_CPROFILE"):          # diagnostic: where the HOST time of a step goes (outside the timed region)
             import cProfile, pstats
             pr = cProfile.Profile()
@@ -278,7 +332,7 @@ def main():
         fence()
         ops.PROFILER = None
         ops.STREAMS = streams
-        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host}
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "eager_ms": eager_ms, "host_first": host_first}
 
     def roofline_of(leg):
         precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
@@ -354,19 +408,32 @@ def main():
     # the gradients of the last backward -- HBM-bound, 16 B read + 12 B written per element
     from glfusion_amd.optim import Adam
     opt = Adam(model.parameters(), lr=3e-4, weight_decay=1e-5)              # main.py:162-165
+    if any(p.grad is None for p in params if p.requires_grad) and main_leg is not None:
+        step()                                                             # (the graph legs release their static gradients)
     opt.step()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    refresh, ops.refresh_weights = ops.refresh_weights, (lambda: None)     # time the Adam kernel alone ...
+    import glfusion_amd.optim as _optim
+    _optim.refresh_weights = ops.refresh_weights
     ev0.record()
     for _ in range(5):
         opt.step()
     ev1.record()
+    ops.refresh_weights = _optim.refresh_weights = refresh                 # ... and the weight-image refresh it triggers
+    for _ in range(5):
+        ops.refresh_weights()
+    ev2.record()
     torch.cuda.synchronize()
     adam_ms = ev0.elapsed_time(ev1) / 5
+    refresh_ms = ev1.elapsed_time(ev2) / 5
     adam_elems = sum(p.numel() for p in model.parameters() if p.grad is not None)
     optimizer_step = {"kernel": "adam_kernel (glf_adam_step, one launch for all parameters)", "ms": round(adam_ms, 3),
                       "elements": adam_elems, "achieved": round(28.0 * adam_elems / adam_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": round(28.0 * adam_elems / adam_ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"}
+                      "unit": "GB/s", "frac": round(28.0 * adam_elems / adam_ms / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm",
+                      "weights_refresh_ms": round(refresh_ms, 3),
+                      "weights_refresh": "glf_weights_refresh: every weight-derived image (layouts, maxima, pre-split fp16 images) in 4 launches; "
+                                         "part of the timed step"}
 
     if rank == 0:
         dt = main_leg["dt"]
@@ -376,6 +443,10 @@ def main():
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "host_enqueue_ms_per_step": round(main_leg["host"] / args.steps * 1e3, 2),
+            "host_enqueue_ms_first_step_idle_queue": round(main_leg["host_first"] * 1e3, 2),
+            "launch": ("one hipGraph replay per step (forward + loss + backward + weight-image refresh recorded once; every kernel "
+                       "runs on every replay)" if use_graph else "eager: every kernel launched from Python"),
+            "eager_ms_per_step": (round(main_leg["eager_ms"], 2) if main_leg["eager_ms"] is not None else None),
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16": "f16 operands (amax-scaled, one MFMA per product), fp32 accumulate, fp32 storage: NOT fp32-equivalent "

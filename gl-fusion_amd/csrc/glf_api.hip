@@ -106,7 +106,7 @@ int ensure_init() {
 }  // namespace glf
 
 extern "C" const char* glf_last_error(void) { return glf::err_buf(); }
-extern "C" int glf_abi_version(void) { return 5; }
+extern "C" int glf_abi_version(void) { return 6; }
 extern "C" int glf_init(void) { return glf::ensure_init(); }
 extern "C" size_t glf_sizeof_gemm_params(void) { return sizeof(glf_gemm_params); }
 extern "C" int glf_set_precision(int mode) {

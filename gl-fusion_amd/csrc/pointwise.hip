@@ -273,7 +273,11 @@ __device__ __forceinline__ unsigned mix64(unsigned long long z) {
     return (unsigned)(z >> 40);                           // 24 bits
 }
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p, float scale,
-                                                      unsigned long long seed) {
+                                                      unsigned long long seed, const unsigned long long* __restrict__ step) {
+    // `step`: a device counter the caller advances once per training step.  A launch recorded in a hipGraph replays with the
+    // SAME `seed` argument every time; the counter is what gives every replay its own mask (forward and backward of one step
+    // read the same value).
+    if (step) seed += *step * 0xD1B54A32D192ED03ull;
     const unsigned thr = (unsigned)(p * 16777216.0f);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         y[i] = (mix64(seed * 0x100000001B3ull + (unsigned long long)i) >= thr) ? x[i] * scale : 0.f;
@@ -606,13 +610,20 @@ extern "C" int glf_bcast_rows_fwd(const float* x, float* y, int ldy, int n, int 
     return glf_bcast_rows_scaled(x, y, ldy, 1.0f, n, p, c, s);
 }
 
-extern "C" int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, glf_stream_t s) {
+extern "C" int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, const uint64_t* step_counter, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y, GLF_ERR_NULL, "dropout: null argument");
     GLF_REQUIRE(numel > 0 && p >= 0.f && p < 1.f, GLF_ERR_BAD_SHAPE, "dropout: numel > 0 and 0 <= p < 1 required");
     hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, glf::S(s), x, y, (long long)numel, p, 1.0f / (1.0f - p),
-                       (unsigned long long)seed);
+                       (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter));
     return glf::check_launch("dropout");
+}
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
+extern "C" int glf_counter_add(uint64_t* counter, uint64_t inc, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(counter, GLF_ERR_NULL, "counter_add: null argument");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, glf::S(s), reinterpret_cast<unsigned long long*>(counter), (unsigned long long)inc);
+    return glf::check_launch("counter_add");
 }
 
 extern "C" int glf_relu_fwd(const float* x, float* y, int64_t numel, glf_stream_t s) {

@@ -69,6 +69,10 @@ class GradAllReducer:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
         self._handles = []
+        # deferred mode (engine.StepGraph): the hooks only copy gradients into the buckets -- work a hipGraph capture can
+        # record -- and every collective is launched by finalize(), after backward (after the graph replay), on the current
+        # stream.  No overlap with backward, nothing but plain eager all_reduce calls on persistent flat tensors.
+        self.deferred = False
         if self.world > 1:
             for p in self._where:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
@@ -93,6 +97,9 @@ class GradAllReducer:
         b, i = self._where[p]
         off = b.offsets[i]
         b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if self.deferred:
+            b.fired[i] = True            # the end-of-backward stream join orders the copy before finalize()
+            return
         if b.flat.is_cuda:
             e = torch.cuda.Event()
             e.record(torch.cuda.current_stream(b.flat.device))
@@ -109,6 +116,18 @@ class GradAllReducer:
         zeros to the collective and keeps `.grad` as it was (None after zero_grad(set_to_none=True)): the optimizer
         skips it exactly as it does on one GPU, so results do not depend on the world size."""
         if self.world == 1:
+            return
+        if self.deferred:
+            # slices of parameters that never fire stay zero (the flat buffer starts zeroed and nothing writes them)
+            works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+            for b, w in zip(self.buckets, works):
+                w.wait()
+                if self.average:
+                    b.flat.div_(self.world)
+                for i, p in enumerate(b.params):
+                    if b.fired[i]:
+                        off = b.offsets[i]
+                        p.grad = b.flat[off:off + p.numel()].view_as(p)
             return
         for b in self.buckets:
             if b.work is None:

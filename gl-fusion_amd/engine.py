@@ -40,6 +40,87 @@ class SyntheticClips:
             yield self.batch()
 
 
+class StepGraph:
+    """One training step -- forward, loss, backward of a FIXED-shape batch -- recorded once as a hipGraph and replayed.
+
+    The eager step issues ~3 200 kernel launches from Python (autograd Functions + ctypes), ~230 ms of host work per 264 ms
+    step at config 2: the launch thread, not the GPU, bounds any further speed-up.  A replay costs one hipGraphLaunch.
+
+        graph = StepGraph(step_fn, params)      # step_fn(): zero-arg closure over STATIC input tensors; returns the loss
+        loss = graph.replay()                   # every kernel of the step runs again; loss / .grad tensors are static
+
+    What makes the step capture-safe (none of it changes results):
+      * weight-derived images are rebuilt by ops.refresh_weights() INSIDE the captured work (static buffers, four launches),
+        so a replay after an optimizer step sees the new parameters;
+      * Dropout masks depend on a device step counter the captured work advances first thing (ops.advance_step);
+      * the slot pools of operand maxima / BatchNorm sums are re-created inside the capture (their zero fill is replayed);
+      * the independent sections of a forward use pairwise different side streams (ops.SECTIONS_DISTINCT; re-using one side
+        stream in two fork/join groups of a capture crashes hipStreamEndCapture on ROCm 7.2);
+      * nothing in the step synchronises the host or allocates outside torch's allocator.
+    Gradient all-reduce stays OUTSIDE the graph (GradAllReducer in deferred mode: the hooks' bucket copies are captured, the
+    collectives are launched by finalize() after each replay).
+    Update parameters only in place (the fused Adam does): the graph holds their addresses."""
+
+    def __init__(self, step_fn, params, warmup: int = 2, reducer=None, refresh_weights: bool = True):
+        self.params = [p for p in params]
+        if not self.params:
+            raise RuntimeError("StepGraph: no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("StepGraph needs CUDA(HIP) parameters: the engine has no CPU fallback")
+        self.device = dev
+        self.reducer = reducer
+        if reducer is not None:
+            reducer.deferred = True
+        prev_distinct, ops.SECTIONS_DISTINCT = ops.SECTIONS_DISTINCT, True
+        self._prev_distinct = prev_distinct
+
+        def body():
+            ops.advance_step(dev)
+            if refresh_weights:
+                ops.refresh_weights()
+            for p in self.params:
+                p.grad = None
+            return step_fn()
+
+        self.stream = torch.cuda.Stream(device=dev)            # warm-up and capture share it (library rings, pools, allocator)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):                    # lazily-created state (caches, job table, rings) settles here
+                out = body()
+                if reducer is not None:
+                    reducer.finalize()
+            del out
+            torch.cuda.synchronize(dev)
+            for p in self.params:
+                p.grad = None
+            ops.reset_capture_pools()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = body()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        self.grads = {p: p.grad for p in self.params if p.grad is not None}      # static tensors the replays write
+
+    def replay(self):
+        """Run the recorded step on the current stream.  Returns step_fn()'s (static) result."""
+        self.graph.replay()
+        if self.reducer is not None and self.reducer.world > 1:
+            self.reducer.finalize()                  # re-points .grad at the reduced bucket slices
+        else:
+            for p, g in self.grads.items():          # an optimizer's zero_grad(set_to_none=True) may have dropped them
+                p.grad = g
+        return self.out
+
+    def release(self) -> None:
+        """Free the graph and its private memory pool."""
+        ops.SECTIONS_DISTINCT = self._prev_distinct
+        if self.reducer is not None:
+            self.reducer.deferred = False
+        self.graph = None
+        self.out = None
+        self.grads = {}
+
+
 class Trainer:
     def __init__(self, config: dict):
         self.config = config

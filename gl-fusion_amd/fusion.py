@@ -24,7 +24,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
-from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
+from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry, WJ_COPY, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
                   tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, packed_hit, pick, zeros)
 
 
@@ -50,25 +50,34 @@ _qkv_cache = {}
 
 def _qkv_weights(params):
     """theta | phi | g weights stacked as ONE [3*ci, c] operand (+ the stacked bias), so the three projections run as a
-    single contraction over the shared input.  Rebuilt (three strided copies by glf_copy_frames, no torch.cat) only when one
-    of the six parameters changed: cached against their version counters, like the conv weight re-layouts in ops.py."""
+    single contraction over the shared input.  The stacked buffers live as long as theta's weight; each of the six slices is
+    a registered weight image (ops._wimage: re-copied when its source parameter changed, or by ops.refresh_weights), and the
+    stacked operand carries the combined version stamp of its sources for the images derived from IT (maximum, transpose,
+    packed forms)."""
     th_w, ph_w, g_w, th_b, ph_b, g_b = params
-    key = id(th_w)
-    sig = tuple((id(t), t._version, t.data_ptr()) for t in params)
-    hit = _qkv_cache.get(key)
-    if hit is not None and hit[0]() is th_w and hit[1] == sig:
-        return hit[2], hit[3]
     ci, c = th_w.shape[0], th_w.shape[1]
-    if ci % 4 == 0:
-        Wcat = torch.empty(3 * ci, c, dtype=torch.float32, device=th_w.device)
-        bcat = torch.empty(3 * ci, dtype=torch.float32, device=th_w.device)
-        for i, (w, b) in enumerate(((th_w, th_b), (ph_w, ph_b), (g_w, g_b))):
-            check(lib.glf_copy_frames(_p(_contig(w.detach())), ci * c, _p(Wcat[i * ci:]), ci * c, 1, ci * c, _stream()), "qkv_weights")
-            check(lib.glf_copy_frames(_p(_contig(b.detach())), ci, _p(bcat[i * ci:]), ci, 1, ci, _stream()), "qkv_bias")
-    else:                                              # odd toy widths only (the 16-byte copy kernel does not apply)
+    if ci % 4 != 0:                                    # odd toy widths only (the 16-byte copy kernel does not apply)
         Wcat = torch.cat([_contig(t.detach()).view(ci, c) for t in (th_w, ph_w, g_w)], dim=0)
         bcat = torch.cat((th_b.detach(), ph_b.detach(), g_b.detach()), dim=0)
-    _qkv_cache[key] = (weakref.ref(th_w, lambda _r, k=key: _qkv_cache.pop(k, None)), sig, Wcat, bcat)
+        return Wcat, bcat
+    key = id(th_w)
+    hit = _qkv_cache.get(key)
+    if hit is None or hit[0]() is not th_w or hit[1].device != th_w.device or hit[1].shape != (3 * ci, c):
+        Wcat = torch.empty(3 * ci, c, dtype=torch.float32, device=th_w.device)
+        bcat = torch.empty(3 * ci, dtype=torch.float32, device=th_w.device)
+        refs = [weakref.ref(t) for t in params]
+        Wcat._glf_version_fn = lambda refs=refs: tuple((r()._version, r().data_ptr()) if r() is not None else None for r in refs)
+        hit = _qkv_cache[key] = (weakref.ref(th_w, lambda _r, k=key: _qkv_cache.pop(k, None)), Wcat, bcat)
+    _, Wcat, bcat = hit
+    for i, (w, b) in enumerate(((th_w, th_b), (ph_w, ph_b), (g_w, g_b))):
+        for t, dst, n in ((w, Wcat[i * ci:(i + 1) * ci], ci * c), (b, bcat[i * ci:(i + 1) * ci], ci)):
+            src = _contig(t.detach())
+            im, fresh = _wimage(t, "qkvcat", WJ_COPY, src, (n, 0, 0), lambda dst=dst: dst)
+            if im.dst.data_ptr() != dst.data_ptr():   # the stacked buffers were re-created: re-register
+                _registry(t.device).drop(im.key)
+                im, fresh = _wimage(t, "qkvcat", WJ_COPY, src, (n, 0, 0), lambda dst=dst: dst)
+            if fresh:
+                check(lib.glf_copy_frames(_p(src), n, _p(im.dst), n, 1, n, _stream()), "qkv_weights")
     return Wcat, bcat
 
 

@@ -139,6 +139,7 @@ class Global_and_Local(_PerViewNetworks):
         views = list(self.view_num)
         hw = x[views[0]].shape[-2:]
         ho, wo = int(hw[0]), int(hw[1])
+        ops.begin_step(x[views[0]].device)
 
         # per view: encoder, then M_cls, M_ctr and the gated local features (ours.py:1795-1816)
         def view_section(v):
@@ -256,6 +257,7 @@ class Global_only(_PerViewNetworks):
 
     def forward(self, x: Dict[str, torch.Tensor]):
         views = list(self.view_num)
+        ops.begin_step(x[views[0]].device)
         hw = x[views[0]].shape[-2:]
         ho, wo = int(hw[0]), int(hw[1])
 
@@ -304,6 +306,7 @@ class Local_only(_PerViewNetworks):
 
     def forward(self, x: Dict[str, torch.Tensor]):
         views = list(self.view_num)
+        ops.begin_step(x[views[0]].device)
         hw = x[views[0]].shape[-2:]
         ho, wo = int(hw[0]), int(hw[1])
 
@@ -365,6 +368,7 @@ class model19(nn.Module):
 
     def forward(self, x: Dict[str, torch.Tensor]):
         views = list(self.view_num)
+        ops.begin_step(x[views[0]].device)
         hw = x[views[0]].shape[-2:]
         ho, wo = int(hw[0]), int(hw[1])
         secs = ops.parallel_sections([lambda v=v: ops.fan_out(self._encode_view(v, x[v]), 3) for v in views])   # fusion / mask_bb / returned f4
@@ -460,6 +464,7 @@ class Global_and_Local_CPS(nn.Module):
         return dict(zip(views, masks)), g_out, l_out
 
     def forward(self, x: Dict[str, torch.Tensor]):
+        ops.begin_step(x[self.view_num[0]].device)
         mask, g_out, l_out = self._net(x, "_1", shared_encoder=False)
         mask_2, _, _ = self._net(x, "_2", shared_encoder=True)
         f4_g, f4_l = {}, {}

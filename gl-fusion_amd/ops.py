@@ -19,7 +19,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import GemmParams, check, lib
+from ._lib import GemmParams, WeightJob, WJ_AMAX, WJ_COPY, WJ_PACK, WJ_PASSES, WJ_PASS_OF, WJ_TAP_MAJOR, WJ_TAP_MAJOR_T, WJ_TRANSPOSE, check, lib
 
 
 # ----------------------------------------------------------------------------------------
@@ -192,12 +192,153 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
         kept_taps = bin(mask).count("1")
         dense = 2.0 * M * N * K * taps * batch
         src_rows = (geo[0] * geo[1] * geo[2]) if geo else None
+        # per-tap rectangle / region launches contract only the in-range part of every kept tap: the EXECUTED work is the
+        # kept taps' work times that fraction (ASPP rate 12: 0.51, rate 24: 0.18)
+        in_range = rect_fraction(gather, geo[3], geo[4], geo[1], geo[2], geo[5], geo[6], geo[8], geo[9], mask) if (rect and geo and gather) else 1.0
         if mode == "tn":
             abytes = 4.0 * batch * (K * M + (src_rows if src_rows else K) * N + M * N * kept_taps)
         else:
             abytes = 4.0 * batch * ((src_rows if src_rows else M) * K + N * K * kept_taps + M * N * (2 if accumulate else 1))
-        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * kept_taps / taps, ev0, ev1,
+        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * kept_taps / taps * in_range, ev0, ev1,
                      (M, N, K, taps, kept_taps, batch, split, geo[8] if geo else 0, geo[9] if geo else 0), abytes))
+
+
+# ----------------------------------------------------------------------------------------
+# weight-derived images: caches + the multi-tensor refresh (include/glfusion.h: glf_weights_refresh)
+# ----------------------------------------------------------------------------------------
+# Everything derived from a parameter -- its max magnitude (f16x3 / f16), the tap-major re-layouts of a k x k weight, the
+# transposed copy of a 1x1 / linear weight, the stacked theta | phi | g operand, and the packed pre-split images of those --
+# is cached against the parameter's version counter and rebuilt after an optimizer step.  One image at a time that is a
+# launch per image (~1 000 per update for the 3-view model); every image therefore also registers itself as a JOB of a device
+# table, and refresh_weights() recomputes all registered images in four launches.  An image keeps its buffer for the life of
+# its parameter (a miss recomputes IN PLACE), so the table -- and a hipGraph that captured a refresh -- stay valid.
+class _WImage:
+    __slots__ = ("key", "owner", "kind", "src", "dst", "amax", "dims", "version", "extra", "__weakref__")
+
+
+class _WeightRegistry:
+    ARENA = 1 << 14
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.images = {}                   # key -> _WImage
+        self.dirty = True
+        self.arena = None                  # float32 [ARENA]: one slot per measured parameter
+        self.free = []
+        self.table = None                  # (device table, pass_first, pass_count, pass_wgs, n_jobs)
+
+    def slot(self) -> torch.Tensor:
+        if self.arena is None:
+            self.arena = zeros(self.ARENA, device=self.dev)
+            self.free = list(range(self.ARENA - 1, -1, -1))
+        if not self.free:
+            raise RuntimeError("glfusion_amd: weight amax arena exhausted (more than 16384 live parameters on one device)")
+        i = self.free.pop()
+        return self.arena[i:i + 1]
+
+    def drop(self, key) -> None:
+        im = self.images.pop(key, None)
+        if im is not None:
+            self.dirty = True
+            if im.kind == WJ_AMAX and self.arena is not None and im.amax is not None:
+                self.free.append(int((im.amax.data_ptr() - self.arena.data_ptr()) // 4))
+
+    def build(self) -> None:
+        ims = sorted(self.images.values(), key=lambda im: WJ_PASS_OF[im.kind])
+        n = len(ims)
+        arr = (WeightJob * max(n, 1))()
+        for j, im in zip(arr, ims):
+            j.src, j.dst = im.src.data_ptr(), (im.dst.data_ptr() if im.dst is not None else 0)
+            j.amax = im.amax.data_ptr() if im.amax is not None else 0
+            j.kind, j.pass_ = im.kind, WJ_PASS_OF[im.kind]
+            j.d0, j.d1, j.d2 = im.dims
+        pf, pc, pw = (C.c_int * WJ_PASSES)(), (C.c_int * WJ_PASSES)(), (C.c_int64 * WJ_PASSES)()
+        check(lib.glf_weights_plan(C.cast(arr, C.c_void_p), n, C.cast(pf, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(pw, C.c_void_p)), "weights_plan")
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = (host.to(self.dev), pf, pc, pw, n)
+        self.dirty = False
+
+    def refresh(self) -> None:
+        if torch.cuda.is_current_stream_capturing() and self.dirty:
+            raise RuntimeError("glfusion_amd: the weight-image table changed inside a graph capture (run a warm-up step first)")
+        if self.dirty:
+            self.build()
+        tab, pf, pc, pw, n = self.table
+        if n:
+            check(lib.glf_weights_refresh(_p(tab), C.cast(pf, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(pw, C.c_void_p),
+                                          _p(self.arena), self.ARENA if self.arena is not None else 0, _stream()), "weights_refresh")
+        for im in self.images.values():
+            o = im.owner()
+            if o is not None:
+                im.version = _wversion(o, im)
+                if im.kind == WJ_AMAX:
+                    o._glf_amax = (o._version, o.data_ptr(), im.amax)
+
+
+_wreg = {}
+
+
+def _registry(dev) -> _WeightRegistry:
+    r = _wreg.get(dev)
+    if r is None:
+        r = _wreg[dev] = _WeightRegistry(dev)
+    return r
+
+
+def _wversion(owner, im=None):
+    """Version stamp of an image owner: the tensor's in-place counter, or -- for a dense operand ASSEMBLED from several
+    parameters (fusion._qkv_weights sets `_glf_version_fn` on it) -- the combined stamp of its sources."""
+    fn = getattr(owner, "_glf_version_fn", None)
+    return fn() if fn is not None else owner._version
+
+
+def _wimage(owner: torch.Tensor, tag: str, kind: int, src: torch.Tensor, dims, make_dst, amax: Optional[torch.Tensor] = None):
+    """The cached image (owner, tag): (image, fresh) with fresh = False when the cached contents are current.  A stale or new
+    image must be (re)computed by the caller into image.dst -- the buffer of a stale image is reused."""
+    reg = _registry(owner.device)
+    key = (id(owner), tag)
+    im = reg.images.get(key)
+    ver = _wversion(owner)
+    if im is not None and im.owner() is owner and im.src.data_ptr() == src.data_ptr() and im.dims == tuple(dims) and \
+            (im.amax is amax or kind == WJ_AMAX):
+        if im.version == ver:
+            return im, False
+        im.version = ver
+        return im, True
+    if im is not None:
+        reg.drop(key)
+    im = _WImage()
+    im.key, im.kind, im.src, im.dims, im.version, im.extra = key, kind, src, tuple(dims), ver, None
+    im.owner = weakref.ref(owner, lambda _r, k=key, d=owner.device: _registry(d).drop(k))
+    im.amax = reg.slot() if kind == WJ_AMAX else amax
+    im.dst = make_dst() if make_dst is not None else None
+    reg.images[key] = im
+    reg.dirty = True
+    return im, True
+
+
+def refresh_weights() -> None:
+    """Recompute every registered weight-derived image from the current parameter values (four launches per device on the
+    current stream) and mark the caches current.  Call after an optimizer step wrote the parameters (glfusion_amd.optim.Adam
+    does); anything not registered yet is still rebuilt lazily by its cache."""
+    for reg in list(_wreg.values()):
+        if reg.images:
+            reg.refresh()
+
+
+def _is_weight(t: torch.Tensor) -> bool:
+    return isinstance(t, torch.nn.Parameter) or hasattr(t, "_glf_version_fn")
+
+
+def weight_amax(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """amax_of for a parameter (or a dense operand assembled from parameters): the scalar lives in the registry's arena."""
+    if _PREC[0] < 2 or not t.is_contiguous():
+        return None
+    im, fresh = _wimage(t, "amax", WJ_AMAX, t, (t.numel(), 0, 0), None)
+    if fresh:
+        zero_(im.amax)
+        check(lib.glf_amax(_p(t), 1, t.numel(), t.numel(), _p(im.amax), _stream()), "amax")
+    return im.amax
 
 
 def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -207,6 +348,8 @@ def amax_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     tensors whose contents are final (raw kernel writes do not bump torch's version counter)."""
     if t is None or _PREC[0] < 2:
         return None
+    if _is_weight(t) and t.is_contiguous():
+        return weight_amax(t)
     hit = getattr(t, "_glf_amax", None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
         return hit[2]
@@ -342,7 +485,6 @@ PRESPLIT = os.environ.get("GLF_PRESPLIT", "1") != "0"
 PRESPLIT_MIN_COLS = int(os.environ.get("GLF_PRESPLIT_MIN_COLS", "1024"))
 WGRAD_STREAM = os.environ.get("GLF_WGRAD_STREAM", "0") != "0"      # a conv's weight gradient on a side stream of its dgrad
 _wgrad_streams = {}
-_packed_cache = {}
 
 
 def presplit_ok(t: torch.Tensor, amax: Optional[torch.Tensor]) -> bool:
@@ -364,13 +506,11 @@ def weight_packed(layout: torch.Tensor, owner: torch.Tensor, tag: str, amax: Opt
     against the owner's version counter and the amax scalar it was scaled with).  None when not applicable."""
     if not presplit_ok(layout, amax):
         return None
-    key = (id(owner), tag)
-    hit = _packed_cache.get(key)
-    if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[3] == layout.data_ptr() and hit[4] is amax:
-        return hit[2]
-    pk = packed_of(layout, amax)
-    _packed_cache[key] = (weakref.ref(owner, lambda _r, k=key: _packed_cache.pop(k, None)), owner._version, pk, layout.data_ptr(), amax)
-    return pk
+    im, fresh = _wimage(owner, "pk:" + tag, WJ_PACK, layout, (layout.numel(), 0, 0), lambda: torch.empty_like(layout), amax)
+    if fresh:
+        cols = layout.shape[-1]
+        check(lib.glf_split_f16_packed(_p(layout), layout.numel() // cols, cols, cols, _p(amax), _p(im.dst), cols, _stream()), "split_f16_packed")
+    return im.dst
 
 
 def packed_hit(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -401,28 +541,37 @@ PRESPLIT_KEEP_FRAC = float(os.environ.get("GLF_PRESPLIT_KEEP_FRAC", "0.5"))
 PRESPLIT_OFF_FRAC = float(os.environ.get("GLF_PRESPLIT_OFF_FRAC", "0.6"))
 _dev_total = {}
 _retain_off = {}
+_retain_step = {}
 
 
 def retain_ok(dev) -> bool:
     """Retained images sit in memory across the peak of the step (end of forward), so the decision cannot be made tensor by
     tensor: once the allocator has been seen above PRESPLIT_OFF_FRAC of the device, retention is off for the rest of the
     process (the workload does not fit with second copies; the first step pays for finding out)."""
+    hit = _retain_step.get(dev)
+    if hit is not None:                       # decided at the first pack of this step (begin_step clears it): no allocator
+        return hit                            # queries per conv, and the step does not change its mind half-way
     tot = _dev_total.get(dev)
     if tot is None:
         tot = _dev_total[dev] = torch.cuda.get_device_properties(dev).total_memory
     off = _retain_off.get(dev, 0)
     if off:
-        if off == 1 and torch.cuda.memory_allocated(dev) < 0.3 * tot:
+        if off == 1 and torch.cuda.memory_allocated(dev) < 0.3 * tot and not torch.cuda.is_current_stream_capturing():
             # first pack of a later step: the images retained before the switch are gone -- hand the pools they inflated
             # back to the device once (a later step needs less than the one that found out)
             torch.cuda.empty_cache()
             _retain_off[dev] = 2
+        _retain_step[dev] = False
         return False
     r = torch.cuda.memory_reserved(dev)
     if r > PRESPLIT_OFF_FRAC * tot:
-        _retain_off[dev] = 1
+        _retain_off[dev] = 1                  # this step keeps what it already retained; the next ones retain nothing
+        _retain_step[dev] = False
         return False
-    return r < PRESPLIT_KEEP_FRAC * tot
+    ok = r < PRESPLIT_KEEP_FRAC * tot
+    if ok:
+        _retain_step[dev] = True              # a "no" below the off threshold is re-examined at the next pack
+    return ok
 
 
 def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor], retain: Optional[bool] = None) -> Optional[torch.Tensor]:
@@ -464,52 +613,45 @@ def pick(t: torch.Tensor, packed: Optional[torch.Tensor], ok: bool):
     return (packed, True) if (ok and packed is not None) else (t, False)
 
 
-_wT_cache = {}
-
-
 def weight_T(w2d: torch.Tensor, owner: torch.Tensor) -> torch.Tensor:
     """Transposed copy [cols][rows] of a 2-D weight view, cached against the owning parameter's version."""
     rows, cols = w2d.shape
-    key = (id(owner), "T2")
-    hit = _wT_cache.get(key)
-    if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[3] == owner.data_ptr():
-        return hit[2]
-    wt = transpose2d(_contig(w2d), rows, cols).view(cols, rows)
-    _wT_cache[key] = (weakref.ref(owner, lambda _r, k=key: _wT_cache.pop(k, None)), owner._version, wt, owner.data_ptr())
-    return wt
+    src = _contig(w2d)
+    im, fresh = _wimage(owner, "T2", WJ_TRANSPOSE, src, (rows, cols, 0),
+                        lambda: torch.empty(cols, rows, dtype=torch.float32, device=owner.device))
+    if fresh:
+        check(lib.glf_transpose2d(_p(src), _p(im.dst), rows, cols, 1, _stream()), "transpose2d")
+    return im.dst
 
 
 def tap_major_T(weight: torch.Tensor) -> torch.Tensor:
     """[tap][Cin][Cout] re-layout (dgrad as an NT contraction), cached like tap_major."""
     co, ci, kh, kw = weight.shape
-    key = (id(weight), "tapT")
-    hit = _wT_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[3] == weight.data_ptr():
-        return hit[2]
-    wt = torch.empty(kh * kw, ci, co, dtype=torch.float32, device=weight.device)
-    check(lib.glf_oihw_to_tap_major_t(_p(_contig(weight.detach())), _p(wt), co, ci, kh * kw, _stream()), "oihw_to_tap_major_t")
-    _wT_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wT_cache.pop(k, None)), weight._version, wt, weight.data_ptr())
-    return wt
-
-
-# weight re-layout cache: OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes.
-# Entries are validated by object identity through a weak reference (id() and data_ptr() of a freed
-# parameter can both be reused by a new one) plus the in-place version counter.
-_wt_cache = {}
+    src = _contig(weight.detach())
+    taps = kh * kw
+    mk = lambda: torch.empty(taps, ci, co, dtype=torch.float32, device=weight.device)
+    if taps == 1:                      # a plain transpose [co][ci] -> [ci][co]
+        im, fresh = _wimage(weight, "tapT", WJ_TRANSPOSE, src, (co, ci, 0), mk)
+        if fresh:
+            check(lib.glf_transpose2d(_p(src), _p(im.dst), co, ci, 1, _stream()), "transpose2d")
+        return im.dst
+    im, fresh = _wimage(weight, "tapT", WJ_TAP_MAJOR_T, src, (co, ci, taps), mk)
+    if fresh:
+        check(lib.glf_oihw_to_tap_major_t(_p(src), _p(im.dst), co, ci, taps, _stream()), "oihw_to_tap_major_t")
+    return im.dst
 
 
 def tap_major(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW -> [tap][Cout][Cin], recomputed only when the parameter changes (a view for 1x1 weights)."""
     co, ci, kh, kw = weight.shape
     if kh * kw == 1:
         return _contig(weight.detach()).view(1, co, ci)
-    key = id(weight)
-    hit = _wt_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[3] == weight.data_ptr():
-        return hit[2]
-    wt = torch.empty(kh * kw, co, ci, dtype=torch.float32, device=weight.device)
-    check(lib.glf_oihw_to_tap_major(_p(_contig(weight.detach())), _p(wt), co, ci, kh * kw, _stream()), "oihw_to_tap_major")
-    _wt_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wt_cache.pop(k, None)), weight._version, wt, weight.data_ptr())
-    return wt
+    src = _contig(weight.detach())
+    im, fresh = _wimage(weight, "tap", WJ_TAP_MAJOR, src, (co, ci, kh * kw),
+                        lambda: torch.empty(kh * kw, co, ci, dtype=torch.float32, device=weight.device))
+    if fresh:
+        check(lib.glf_oihw_to_tap_major(_p(src), _p(im.dst), co, ci, kh * kw, _stream()), "oihw_to_tap_major")
+    return im.dst
 
 
 # ----------------------------------------------------------------------------------------
@@ -1068,7 +1210,7 @@ class DropoutFn(Function):
     def forward(ctx, x, p: float, seed: int):
         x = _contig(_chk(x, "dropout input"))
         y = torch.empty_like(x)
-        check(lib.glf_dropout(_p(x), _p(y), x.numel(), p, seed, _stream()), "dropout")
+        check(lib.glf_dropout(_p(x), _p(y), x.numel(), p, seed, _p(step_counter(x.device)), _stream()), "dropout")
         ctx.cfg = (p, seed)
         return y
 
@@ -1078,7 +1220,7 @@ class DropoutFn(Function):
         p, seed = ctx.cfg
         dy = _contig(dy)
         dx = torch.empty_like(dy)
-        check(lib.glf_dropout(_p(dy), _p(dx), dy.numel(), p, seed, _stream()), "dropout_bwd")
+        check(lib.glf_dropout(_p(dy), _p(dx), dy.numel(), p, seed, _p(step_counter(dy.device)), _stream()), "dropout_bwd")
         return dx, None, None
 
 
@@ -1269,6 +1411,46 @@ def _walk_tensors(obj):
             yield from _walk_tensors(v)
 
 
+# GLF_SECTIONS_DISTINCT=1: the stream counter restarts only at begin_step() (the models call it at the top of forward), so
+# successive top-level parallel_sections calls of one forward get DIFFERENT side streams instead of re-using 0, 1, 2 ...
+SECTIONS_DISTINCT = os.environ.get("GLF_SECTIONS_DISTINCT", "0") != "0"
+
+
+_step_counters = {}
+
+
+def step_counter(dev) -> torch.Tensor:
+    """Device uint64 (held as int64) that advance_step() moves once per captured training step; the dropout kernels mix it into their
+    seed, so a step replayed from a hipGraph (whose launches carry fixed seed arguments) still draws fresh masks."""
+    t = _step_counters.get(dev)
+    if t is None:
+        t = _step_counters[dev] = zeros(1, dtype=torch.int64, device=dev)
+    return t
+
+
+def begin_step(dev=None) -> None:
+    """Top of a model forward: restart the side-stream assignment and decide ONCE whether this step retains pre-split images
+    from forward to backward (see retain_ok)."""
+    for pool in _side.values():
+        if pool[2] == 0:
+            pool[1] = 0
+    _retain_step.clear()
+
+
+def advance_step(dev) -> None:
+    """Advance the device step counter (one tiny launch).  A captured training step calls it ONCE, first thing, whatever the
+    number of forwards it contains -- forward and backward of a Dropout must read the same value.  Eager steps need not call
+    it: their dropout seeds are drawn on the host per call."""
+    check(lib.glf_counter_add(_p(step_counter(dev)), 1, _stream()), "counter_add")
+
+
+def reset_capture_pools() -> None:
+    """Before a hipGraph capture: drop the pre-zeroed slot pools so that the pools the captured step uses are created -- and
+    zero-filled -- INSIDE the capture (a replay then starts from zeroed maxima / statistics like an eager step does)."""
+    _amax_pool.clear()
+    _stats_pool.clear()
+
+
 def parallel_sections(fns):
     """Run the callables as independent sections, section i on side stream i, and join them on the current
     stream.  Returns their results in order."""
@@ -1283,7 +1465,7 @@ def parallel_sections(fns):
     # own and a given section lands on the SAME stream every step (the caching allocator keeps one pool per stream;
     # a wandering assignment would re-allocate every activation).  A stream shared by two sections only adds an
     # ordering between them.
-    if pool[2] == 0:
+    if pool[2] == 0 and not SECTIONS_DISTINCT:
         pool[1] = 0
     pool[2] += 1
     used = []

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .ops import _p, _stream
+from .ops import _p, _stream, refresh_weights
 
 CHUNK = 1 << 16          # elements per table row (one workgroup pass)
 
@@ -124,4 +124,7 @@ class Adam(torch.optim.Optimizer):
                 # the kernel writes through raw pointers: tell autograd (and every cache keyed on `_version`: the
                 # tap-major / transposed / pre-split weight layouts and the measured maxima in ops.py) that these changed
                 torch.autograd.graph.increment_version(updated)
+        # ... and rebuild every registered weight-derived image in four launches (instead of ~5 launches per conv when the
+        # next forward finds its caches stale)
+        refresh_weights()
         return loss

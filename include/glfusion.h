@@ -239,6 +239,45 @@ int glf_oihw_to_tap_major_t(const float* w, float* out, int cout, int cin, int t
 int glf_transpose2d(const float* src, float* dst, int rows, int cols, int batch, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
+ * Multi-tensor weight refresh.  Everything the contraction kernels derive from the parameters -- tap-major re-layouts
+ * (forward / wgrad order and the transposed dgrad order), transposed copies of 1x1 / linear weights, the stacked
+ * theta | phi | g operand of a fusion block (ours.py:866,878-879), each parameter's max magnitude (precision 3 / 4) and
+ * the packed pre-split images of all of those -- has to be rebuilt after EVERY optimizer step (main.py:243).  Through the
+ * per-tensor entry points above that is one launch per image, ~1 000 launches per update for the 3-view model; this block
+ * does it in one launch per dependency level.  The caller describes every derived image once as a glf_weight_job (pointers
+ * are caller-owned and must stay valid), sorts the jobs by `pass`, lets glf_weights_plan fill in the grid bookkeeping,
+ * copies the table to the device, and calls glf_weights_refresh after each update.  Results are bit-identical to the
+ * per-tensor entry points.
+ * ------------------------------------------------------------------------------------- */
+enum {
+    GLF_WJ_COPY = 0,        /* dst[i] = src[i], d0 elements                                   (pass 0) */
+    GLF_WJ_AMAX = 1,        /* *amax = max(*amax, max|src|), d0 elements; dst unused           (pass 1) */
+    GLF_WJ_TAP_MAJOR = 2,   /* src OIHW [d0=Cout][d1=Cin][d2=taps] -> dst [taps][Cout][Cin]     (pass 2) */
+    GLF_WJ_TAP_MAJOR_T = 3, /* ... -> dst [taps][Cin][Cout]                                     (pass 2) */
+    GLF_WJ_TRANSPOSE = 4,   /* src [d0=rows][d1=cols] -> dst [cols][rows]                       (pass 2) */
+    GLF_WJ_PACK = 5,        /* dst = packed pre-split image of src (d0 elements, % 4 == 0, both 16-byte aligned)
+                               scaled by *amax, as glf_split_f16_packed                          (pass 3) */
+    GLF_WJ_PASSES = 4
+};
+typedef struct {
+    const float* src;
+    float* dst;
+    float* amax;            /* AMAX: the slot to raise (inside the arena glf_weights_refresh zero-fills); PACK: the scale source */
+    int32_t kind;           /* GLF_WJ_*                                                        */
+    int32_t pass;           /* dependency level, 0 .. GLF_WJ_PASSES-1; the table is sorted by it */
+    int32_t d0, d1, d2;     /* extents, see the kinds                                          */
+    int32_t reserved;
+    int64_t first_wg;       /* filled by glf_weights_plan: first workgroup of this job in its pass */
+} glf_weight_job;
+/* Validates a HOST table sorted by pass, fills first_wg of every job and, per pass p (arrays of GLF_WJ_PASSES entries),
+ * the index of its first job, its job count and its workgroup count.  No device work. */
+int glf_weights_plan(glf_weight_job* jobs_host, int n_jobs, int* pass_first, int* pass_count, int64_t* pass_wgs);
+/* Zero-fills amax_arena[0 .. amax_floats) (may be NULL / 0) and runs the passes of a planned table that has been copied
+ * to device memory (jobs_dev), in order, on `s`. */
+int glf_weights_refresh(const glf_weight_job* jobs_dev, const int* pass_first, const int* pass_count, const int64_t* pass_wgs,
+                        float* amax_arena, int64_t amax_floats, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
  * Stem (a2): Conv2d(1,64,7,stride 1,pad 2)+bias (models/_utils.py:192; used ours.py:1796).
  * x [N][H][W] (C=1), w [Cout][49], y [N][Ho][Wo][Cout] with Ho = H + 2*pad - 6.
  * ------------------------------------------------------------------------------------- */
@@ -310,8 +349,13 @@ int glf_bcast_rows_scaled(const float* x, float* y, int ldy, float scale, int n,
 /* Stand-alone nn.ReLU (the fused paths apply it inside glf_bn_apply). */
 int glf_relu_fwd(const float* x, float* y, int64_t numel, glf_stream_t s);
 int glf_relu_bwd(const float* dy, const float* y, float* dx, int64_t numel, glf_stream_t s);
-/* Dropout with a counter-based generator: keep iff hash(seed, element) >= p.  y = x*keep/(1-p). */
-int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, glf_stream_t s);
+/* Dropout with a counter-based generator: keep iff hash(seed', element) >= p.  y = x*keep/(1-p).
+ * seed' = seed + *step_counter * odd constant when step_counter (a DEVICE uint64, may be NULL) is given: a launch recorded in
+ * a hipGraph replays with the same `seed` argument, the counter -- advanced once per training step by glf_counter_add, itself
+ * part of the graph -- gives every replay its own masks (deeplabv3.py:159 Dropout(0.5), a fresh mask per forward). */
+int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, const uint64_t* step_counter, glf_stream_t s);
+/* *counter += inc (a device uint64), stream-ordered. */
+int glf_counter_add(uint64_t* counter, uint64_t inc, glf_stream_t s);
 /* Local gate (a5, ours.py:1802-1816): a[r] = sigmoid(w * max_c sigmoid(cls[r][c]) * sigmoid(ctr[r])),
  * y[r][:] = f[r][:] * a[r].  argmax (int32 per row) is saved for backward. */
 int glf_gate_fwd(const float* cls, int ncls, const float* ctr, const float* f, float* y, float* a,

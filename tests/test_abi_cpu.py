@@ -22,7 +22,7 @@ def test_header_parses_and_library_exports_every_symbol():
     for name in protos:
         assert hasattr(dll, name), f"libglfusion_hip.so does not export {name}"
     dll.glf_abi_version.restype = ctypes.c_int
-    assert dll.glf_abi_version() == 5
+    assert dll.glf_abi_version() == 6
     # pure host-side queries work without a GPU
     dll.glf_bn_workspace.restype = ctypes.c_size_t
     dll.glf_bn_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -140,3 +140,33 @@ def test_conv_plan_matches_host_policy():
                 assert (pl.tap_mask, pl.rect, pl.split) == (mask, int(rect), split), (prec, "wgrad", n, h, cin, cout, k, dil, pl.split, split)
         finally:
             ops.set_precision("f32")
+
+
+def test_weights_plan_bookkeeping():
+    """glf_weights_plan is host-only: grid bookkeeping of the multi-tensor weight refresh (first workgroup of every job in
+    its pass, jobs / workgroups per pass) and its refusals (unsorted passes, misaligned packed images)."""
+    import ctypes as C
+    from glfusion_amd._lib import WeightJob, WJ_AMAX, WJ_COPY, WJ_PACK, WJ_PASSES, WJ_TAP_MAJOR, WJ_TRANSPOSE, lib
+    jobs = (WeightJob * 5)()
+    spec = [(WJ_COPY, 0, (5000, 0, 0)), (WJ_AMAX, 1, (4096, 0, 0)), (WJ_AMAX, 1, (4097, 0, 0)), (WJ_TAP_MAJOR, 2, (64, 64, 9)),
+            (WJ_PACK, 3, (8192, 0, 0))]
+    for j, (kind, ps, dims) in zip(jobs, spec):
+        j.src, j.dst, j.amax, j.kind, j.pass_ = 0x10000, 0x20000, 0x30000, kind, ps
+        j.d0, j.d1, j.d2 = dims
+    pf, pc, pw = (C.c_int * WJ_PASSES)(), (C.c_int * WJ_PASSES)(), (C.c_int64 * WJ_PASSES)()
+    args = (C.cast(pf, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(pw, C.c_void_p))
+    assert lib.glf_weights_plan(C.cast(jobs, C.c_void_p), 5, *args) == 0
+    assert list(pf) == [0, 1, 3, 4] and list(pc) == [1, 2, 1, 1]
+    assert list(pw) == [2, 1 + 2, (64 * 64 * 9 + 4095) // 4096, 2]
+    assert [j.first_wg for j in jobs] == [0, 0, 1, 0, 0]
+    # a 65 x 33 transpose: 3 x 2 tiles of 32 x 32
+    t = (WeightJob * 1)()
+    t[0].src, t[0].dst, t[0].kind, t[0].pass_, t[0].d0, t[0].d1 = 0x10000, 0x20000, WJ_TRANSPOSE, 2, 65, 33
+    assert lib.glf_weights_plan(C.cast(t, C.c_void_p), 1, *args) == 0 and list(pw)[2] == 6
+    # refusals
+    jobs[0].pass_ = 2                                  # not sorted by pass
+    assert lib.glf_weights_plan(C.cast(jobs, C.c_void_p), 5, *args) != 0
+    jobs[0].pass_ = 0
+    jobs[4].src = 0x10004                              # packed image source not 16-byte aligned
+    assert lib.glf_weights_plan(C.cast(jobs, C.c_void_p), 5, *args) != 0
+    assert b"aligned" in lib.glf_last_error()

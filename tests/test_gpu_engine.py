@@ -172,3 +172,134 @@ def test_three_adam_steps_see_fresh_weights(prec):
             assert abs(a - b) <= tol * abs(b), (got, want)
     finally:
         ops.set_precision("f32")
+
+
+def _small_model(views=("1",), salt=3, dropout=0.0):
+    from glfusion_amd.models import Global_and_Local
+    ref = orc.Global_and_Local(list(views))
+    orc.closed_form_fill(ref, salt=salt)
+    model = Global_and_Local(list(views))
+    model.load_state_dict(ref.state_dict(), strict=True)
+    if dropout is not None:
+        orc.set_dropout(model, dropout)
+    return model.to(DEV).train()
+
+
+def test_weights_refresh_is_bit_identical_to_per_tensor_rebuild():
+    """ops.refresh_weights() (glf_weights_refresh: every weight-derived image in four launches) against the per-tensor cache
+    misses it replaces: same buffers, bit-identical contents, caches current afterwards."""
+    from glfusion_amd import ops
+    ops.set_precision("f16x3")
+    try:
+        views, n = ["1"], 2
+        model = _small_model(views)
+        imgs = {v: t.to(DEV) for v, t in orc.closed_form_images(views, n, 112, 112).items()}
+        tgts = {v: t.to(DEV) for v, t in orc.closed_form_targets(views, n).items()}
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            pred = model(imgs)[0]
+            sum(ops.bce_with_logits_sum(pred[v], tgts[v]) for v in views).backward()
+
+        step()                                             # registers every image this model's step uses
+        reg = ops._registry(torch.device(DEV, torch.cuda.current_device()))
+        mine = {id(p) for p in model.parameters()}
+        stacked = {id(im.owner()) for im in reg.images.values() if im.owner() is not None and hasattr(im.owner(), "_glf_version_fn")}
+        keys = [k for k, im in reg.images.items() if k[0] in mine or k[0] in stacked]
+        kinds = {reg.images[k].kind for k in keys}
+        assert kinds == {0, 1, 2, 3, 4, 5}, kinds          # copy, amax, both tap-major forms, transpose, packed
+        assert len(keys) > 300
+        with torch.no_grad():
+            for i, p in enumerate(model.parameters()):
+                p.mul_(1.0 + 0.01 * ((i % 7) - 3))          # new values, version counters bumped
+        ops.refresh_weights()
+        torch.cuda.synchronize()
+        snap, ptrs = {}, {}
+        for k in keys:
+            im = reg.images[k]
+            buf = im.amax if im.kind == 1 else im.dst
+            snap[k], ptrs[k] = buf.clone(), buf.data_ptr()
+            o = im.owner()
+            assert im.version == ops._wversion(o), "cache not marked current by the refresh"
+        # the same values again through the per-tensor path: mark every parameter changed, let the caches miss one by one
+        torch.autograd.graph.increment_version(list(model.parameters()))
+        step()
+        torch.cuda.synchronize()
+        for k in keys:
+            im = reg.images[k]
+            buf = im.amax if im.kind == 1 else im.dst
+            assert buf.data_ptr() == ptrs[k], "an image moved: a captured refresh would write a dead buffer"
+            assert torch.equal(buf.view(torch.int32), snap[k].view(torch.int32)), f"image {k[1]} (kind {im.kind}) differs"
+    finally:
+        ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_step_graph_replay_matches_eager_step(prec):
+    """engine.StepGraph: the step recorded as ONE hipGraph gives the eager step's loss and gradients; a replay after the fused
+    Adam wrote the parameters sees the new weights (the weight-image refresh is part of the recorded work); Dropout draws a new
+    mask on every replay."""
+    from glfusion_amd import ops
+    from glfusion_amd.engine import StepGraph
+    from glfusion_amd.optim import Adam
+    ops.set_precision(prec)
+    try:
+        views, n = ["1"], 4
+        imgs = {v: t.to(DEV) for v, t in orc.closed_form_images(views, n, 112, 112).items()}
+        tgts = {v: t.to(DEV) for v, t in orc.closed_form_targets(views, n).items()}
+        lr = 1e-4
+
+        def make(dropout):
+            model = _small_model(views, salt=4, dropout=dropout)
+            params = [p for nm, p in model.named_parameters() if not nm.startswith("network.")]
+
+            def core():
+                pred = model(imgs)[0]
+                loss = sum(ops.bce_with_logits_sum(pred[v], tgts[v]) for v in views)
+                loss.backward()
+                return loss.detach()
+            return model, params, core
+
+        # eager trajectory: step, Adam, step
+        model, params, core = make(0.0)
+        opt = Adam(params, lr=lr)
+        want = []
+        for _ in range(2):
+            for p in params:
+                p.grad = None
+            want.append((float(core()), {i: p.grad.clone() for i, p in enumerate(params) if p.grad is not None}))
+            opt.step()
+        del model, opt
+        # the same through the graph
+        model, params, core = make(0.0)
+        opt = Adam(params, lr=lr)
+        sg = StepGraph(core, params, warmup=2)
+        for k in range(2):
+            loss = float(sg.replay())
+            # (after an Adam update the two runs' rounding noise has been amplified by its sign-like first step)
+            assert abs(loss - want[k][0]) <= (1e-6 if k == 0 else 2e-5) * abs(want[k][0]), (k, loss, want[k][0])
+            # floor: a conv bias in front of a train-mode BatchNorm has a structurally zero gradient -- what two runs hold
+            # there is rounding noise of the float-atomic ASPP rectangles, different from run to run in eager mode too
+            floor = 2e-5 * max(float(g.norm()) for g in want[k][1].values())
+            for i, p in enumerate(params):
+                if i in want[k][1]:
+                    ref = want[k][1][i]
+                    err = float((p.grad - ref).norm())
+                    assert err <= (2e-5 if k == 0 else 2e-3) * float(ref.norm()) + floor, (k, i, err, float(ref.norm()), floor)
+                else:
+                    assert p.grad is None
+            opt.zero_grad(set_to_none=True)
+            sg.replay()                                    # gradients come back after set_to_none
+            assert all(p.grad is not None for i, p in enumerate(params) if i in want[k][1])
+            opt.step()
+        sg.release()
+        del sg, model, opt
+        # Dropout(0.5) active: every replay draws its own mask
+        model, params, core = make(None)
+        sg = StepGraph(core, params, warmup=1)
+        losses = [float(sg.replay()) for _ in range(3)]
+        assert len({round(l, 3) for l in losses}) == 3, losses
+        sg.release()
+    finally:
+        ops.set_precision("f32")
