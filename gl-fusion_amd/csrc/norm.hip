@@ -7,6 +7,7 @@
 //   * the TPAVI tail z = LayerNorm_C(BN(W_z y) + x) runs one wavefront per row with shuffle
 //     reductions only (no LDS, no barrier).
 #include "glf_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -132,6 +133,66 @@ __global__ __launch_bounds__(RT) void colreduce_kernel(Op op, int rows, int c, i
     }
 }
 
+// BatchNorm-backward stage 1 with two more per-channel reductions over the same elements: max |dy'| and max |xhat|.  They cost
+// no memory traffic (the values are in registers for the sums) and let the finalize kernel bound max |dx| BEFORE dx is
+// written -- which is what allows bn_bwd_apply to emit dx directly as the packed pre-split fp16 image the consuming
+// contractions read (the image's power-of-two scale must be known when the first element is written).
+// pmax[0][slice][c] = max |dy'|, pmax[1][slice][c] = max |xhat| (floats, behind the f64 partials).
+__global__ __launch_bounds__(RT) void bnbwd_reduce_kernel(OpBnBwd op, int rows, int c, int slices, double* __restrict__ partial,
+                                                          float* __restrict__ pmax) {
+    __shared__ double sh_a[RT * 4];
+    __shared__ double sh_b[RT * 4];
+    __shared__ float sh_m[RT * 8];
+    const int tid = threadIdx.x;
+    const int c4 = c >> 2;
+    const int tpr = c4 < RT ? c4 : RT;            // threads per row
+    const int rpp = RT / tpr;                     // rows per pass
+    const int ct = tid % tpr, rl = tid / tpr;
+    const int slice = blockIdx.x;
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = slice * per, r1 = min(rows, r0 + per);
+    for (int cb = blockIdx.y * tpr; cb < c4; cb += gridDim.y * tpr) {
+        const int cc = cb + ct;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        float mg[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cc < c4 && rl < rpp) {
+            const float4 mu = *reinterpret_cast<const float4*>(op.mean + cc * 4);
+            const float4 is = *reinterpret_cast<const float4*>(op.invstd + cc * 4);
+            for (int r = r0 + rl; r < r1; r += rpp) {
+                float4 a, b;
+                op(r, cc * 4, a, b);
+                a0 += a.x; a1 += a.y; a2 += a.z; a3 += a.w;
+                b0 += b.x; b1 += b.y; b2 += b.z; b3 += b.w;
+                const float4 xx = *reinterpret_cast<const float4*>(op.x + (long long)r * op.ldx + cc * 4);   // (the load op() made: CSE'd)
+                mg[0] = fmaxf(mg[0], fabsf(a.x)); mg[1] = fmaxf(mg[1], fabsf(a.y)); mg[2] = fmaxf(mg[2], fabsf(a.z)); mg[3] = fmaxf(mg[3], fabsf(a.w));
+                mx[0] = fmaxf(mx[0], fabsf((xx.x - mu.x) * is.x)); mx[1] = fmaxf(mx[1], fabsf((xx.y - mu.y) * is.y));
+                mx[2] = fmaxf(mx[2], fabsf((xx.z - mu.z) * is.z)); mx[3] = fmaxf(mx[3], fabsf((xx.w - mu.w) * is.w));
+            }
+        }
+        sh_a[tid * 4 + 0] = a0; sh_a[tid * 4 + 1] = a1; sh_a[tid * 4 + 2] = a2; sh_a[tid * 4 + 3] = a3;
+        sh_b[tid * 4 + 0] = b0; sh_b[tid * 4 + 1] = b1; sh_b[tid * 4 + 2] = b2; sh_b[tid * 4 + 3] = b3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sh_m[tid * 8 + j] = mg[j]; sh_m[tid * 8 + 4 + j] = mx[j]; }
+        __syncthreads();
+        if (rl == 0 && cc < c4) {
+            for (int q = 1; q < rpp; ++q) {
+                const int o = (q * tpr + ct) * 4;
+                a0 += sh_a[o]; a1 += sh_a[o + 1]; a2 += sh_a[o + 2]; a3 += sh_a[o + 3];
+                b0 += sh_b[o]; b1 += sh_b[o + 1]; b2 += sh_b[o + 2]; b3 += sh_b[o + 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mg[j] = fmaxf(mg[j], sh_m[2 * o + j]); mx[j] = fmaxf(mx[j], sh_m[2 * o + 4 + j]); }
+            }
+            double* pa = partial + (long long)slice * c + cc * 4;
+            double* pb = partial + (long long)(slices + slice) * c + cc * 4;
+            pa[0] = a0; pa[1] = a1; pa[2] = a2; pa[3] = a3;
+            pb[0] = b0; pb[1] = b1; pb[2] = b2; pb[3] = b3;
+            *reinterpret_cast<float4*>(pmax + (long long)slice * c + cc * 4) = make_float4(mg[0], mg[1], mg[2], mg[3]);
+            *reinterpret_cast<float4*>(pmax + (long long)(slices + slice) * c + cc * 4) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        }
+        __syncthreads();
+    }
+}
+
 // stage 2: fold the per-slice partials.  One workgroup = 16 channels x 16 slice lanes (a serial loop over
 // up to 1024 slices per channel on a single thread was 13% of the whole step in the first profile).
 constexpr int FIN_CH = 16, FIN_LANES = 16;
@@ -193,6 +254,48 @@ __global__ __launch_bounds__(256) void sum_finalize(const double* __restrict__ p
     if (lane != 0 || ch >= c) return;
     if (out_a) out_a[ch] = (float)s;
     if (out_b) out_b[ch] = (float)q;
+}
+
+// BatchNorm-backward stage 2 for the packed-dx path: the two sums, and an upper bound of max |dx| over the whole tensor into
+// *bound (a zeroed device float; non-negative floats order like their bit patterns):
+//   training: |dx| = |gamma invstd| |g - (s1 + xhat s2) / n| <= |gamma invstd| (max|g| + (|s1| + max|xhat| |s2|) / n)   per channel
+//   eval    : |dx| = |gamma invstd| |g|
+// (x 1.0001: the apply kernel rounds its fp32 expression differently; the image's power-of-two scale leaves two bits of
+// fp16 headroom above the bound anyway)
+__global__ __launch_bounds__(256) void bnbwd_finalize(const double* __restrict__ partial, const float* __restrict__ pmax, int slices, int c,
+                                                      const float* __restrict__ gamma, const float* __restrict__ invstd, float inv_n,
+                                                      int training, float* out_a, float* out_b, float* __restrict__ bound) {
+    __shared__ double sh[512];
+    __shared__ float shm[512];
+    const int cx = threadIdx.x % FIN_CH, lane = threadIdx.x / FIN_CH;
+    const int ch = blockIdx.x * FIN_CH + cx;
+    double s, q;
+    fold_partials(partial, slices, c, ch, lane, s, q, sh);
+    float mg = 0.f, mx = 0.f;
+    if (ch < c) {
+        float g1 = 0.f, x1 = 0.f, g2 = 0.f, x2 = 0.f, g3 = 0.f, x3 = 0.f;       // independent chains: the loop is latency-bound
+        int i = lane;
+        for (; i + 3 * FIN_LANES < slices; i += 4 * FIN_LANES) {
+            mg = fmaxf(mg, pmax[(long long)i * c + ch]);                      mx = fmaxf(mx, pmax[(long long)(slices + i) * c + ch]);
+            g1 = fmaxf(g1, pmax[(long long)(i + FIN_LANES) * c + ch]);        x1 = fmaxf(x1, pmax[(long long)(slices + i + FIN_LANES) * c + ch]);
+            g2 = fmaxf(g2, pmax[(long long)(i + 2 * FIN_LANES) * c + ch]);    x2 = fmaxf(x2, pmax[(long long)(slices + i + 2 * FIN_LANES) * c + ch]);
+            g3 = fmaxf(g3, pmax[(long long)(i + 3 * FIN_LANES) * c + ch]);    x3 = fmaxf(x3, pmax[(long long)(slices + i + 3 * FIN_LANES) * c + ch]);
+        }
+        for (; i < slices; i += FIN_LANES) {
+            mg = fmaxf(mg, pmax[(long long)i * c + ch]);
+            mx = fmaxf(mx, pmax[(long long)(slices + i) * c + ch]);
+        }
+        mg = fmaxf(fmaxf(mg, g1), fmaxf(g2, g3)); mx = fmaxf(fmaxf(mx, x1), fmaxf(x2, x3));
+    }
+    shm[threadIdx.x] = mg; shm[256 + threadIdx.x] = mx;
+    __syncthreads();
+    if (lane != 0 || ch >= c) return;
+    for (int l = 1; l < FIN_LANES; ++l) { mg = fmaxf(mg, shm[threadIdx.x + l * FIN_CH]); mx = fmaxf(mx, shm[256 + threadIdx.x + l * FIN_CH]); }
+    if (out_a) out_a[ch] = (float)s;
+    if (out_b) out_b[ch] = (float)q;
+    const float k = fabsf(gamma[ch] * invstd[ch]);
+    const float b = 1.0001f * k * (training ? mg + inv_n * (fabsf((float)s) + mx * fabsf((float)q)) : mg);
+    if (b > 0.f && b < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(b));
 }
 
 // running-statistics update of a train-mode BatchNorm replayed from its saved batch statistics (mean, invstd): what a second
@@ -257,14 +360,70 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (amax_out) block_amax(am, amax_out);
 }
 
+// BatchNorm apply with the statistics FINISHED IN THE KERNEL: the producing contraction's epilogue left (sum x, sum x^2) per
+// channel in `sums` (glf_gemm_params.colstats); every workgroup turns them into mean / invstd for all channels in LDS (the
+// same double-precision expressions as bn_stats_finalize: results are bit-identical to glf_bn_stats_from_sums + glf_bn_apply),
+// workgroup 0 also writes them out for the backward pass and updates the running statistics.  One launch instead of two per
+// BatchNorm, and no tiny kernel on the dependent chain conv -> statistics -> apply -> next conv.
+constexpr int APPLY_MAX_C = 4096;
+__global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res, int ldr,
+                                                            float* __restrict__ y, int ldy, const double* __restrict__ sums, int rows, int c,
+                                                            float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out, float* rmean, float* rvar,
+                                                            long long* nbt, long long total4, int c4, int relu, float* __restrict__ amax_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_coef[];       // [2][c]: mean, invstd
+    float* s_mean = s_coef;
+    float* s_is = s_coef + c;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        const double m = sums[ch] / rows;
+        double var = sums[c + ch] / rows - m * m;
+        if (var < 0) var = 0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[ch] = mf; s_is[ch] = isf;
+        if (blockIdx.x == 0) {
+            mean_out[ch] = mf; invstd_out[ch] = isf;
+            if (rmean) {
+                const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+                rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)m;
+                rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    __syncthreads();
+    float am = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int cc = (int)(i - r * c4) * 4;
+        const float4 xx = *reinterpret_cast<const float4*>(x + r * ldx + cc);
+        const float4 mu = *reinterpret_cast<const float4*>(s_mean + cc);
+        const float4 is = *reinterpret_cast<const float4*>(s_is + cc);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
+        const float4 be = *reinterpret_cast<const float4*>(beta + cc);
+        float4 o = make_float4(bn_val(xx.x, mu.x, is.x, ga.x, be.x), bn_val(xx.y, mu.y, is.y, ga.y, be.y),
+                               bn_val(xx.z, mu.z, is.z, ga.z, be.z), bn_val(xx.w, mu.w, is.w, ga.w, be.w));
+        if (res) {
+            const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + cc);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (amax_out) block_amax(am, amax_out);
+}
+
 // dx = gamma*invstd*(dy' - [sum_dy/n + xhat*sum_dyx/n]) ; dres = dy'
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ y, int ldy, Coef k,
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
                                                            long long total4, int c4, int relu, int training, float inv_n,
-                                                           float* __restrict__ amax_out) {
-    float am = 0.f;
+                                                           float* __restrict__ amax_out, int packed) {
+    // packed != 0: dx is written as the packed pre-split fp16 image (glf_split_f16_packed's format) scaled by *amax_out, which
+    // then holds an upper bound of max |dx| computed by bnbwd_finalize (not a by-product of this kernel)
+    float am = 0.f, sc = 1.f, sc_inv = 1.f;
+    if (packed) pow2_scale(amax_out, sc, sc_inv);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
@@ -300,10 +459,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         } else {
             o = make_float4(g.x * ga.x * is.x, g.y * ga.y * is.y, g.z * ga.z * is.z, g.w * ga.w * is.w);
         }
+        if (packed) {
+            const SplitH sp = split4h(o, sc);
+            const float2 h = __builtin_bit_cast(float2, sp.h), l = __builtin_bit_cast(float2, sp.l);
+            o = make_float4(h.x, h.y, l.x, l.y);
+        } else {
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
         *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (amax_out) block_amax(am, amax_out);
+    if (amax_out && !packed) block_amax(am, amax_out);
 }
 
 // ---- TPAVI tail: one wavefront per row ---------------------------------------------------
@@ -319,7 +484,8 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bn_res_ln_kernel(const float* __restrict__ w, const float* __restrict__ x, Coef bn,
                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
                                                         float* __restrict__ z, float* __restrict__ row_mean, float* __restrict__ row_rstd,
-                                                        const float* __restrict__ dz, float* __restrict__ du, int rows, int c) {
+                                                        const float* __restrict__ dz, float* __restrict__ du, int rows, int c,
+                                                        float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -357,6 +523,7 @@ __global__ __launch_bounds__(256) void bn_res_ln_kernel(const float* __restrict_
             }
         rstd = 1.0f / sqrtf(wave_sum(q) / c + eps);
         if (lane == 0) { row_mean[row] = mean; row_rstd[row] = rstd; }
+        float am = 0.f;
 #pragma unroll
         for (int v = 0; v < LN_NV; ++v) {
             const int cc = lane + 64 * v;
@@ -364,10 +531,16 @@ __global__ __launch_bounds__(256) void bn_res_ln_kernel(const float* __restrict_
                 const int ch = cc * 4;
                 const float4 g = *reinterpret_cast<const float4*>(ln_g + ch);
                 const float4 b = *reinterpret_cast<const float4*>(ln_b + ch);
-                *reinterpret_cast<float4*>(z + base + ch) =
-                    make_float4((u[v].x - mean) * rstd * g.x + b.x, (u[v].y - mean) * rstd * g.y + b.y,
-                                (u[v].z - mean) * rstd * g.z + b.z, (u[v].w - mean) * rstd * g.w + b.w);
+                const float4 o = make_float4((u[v].x - mean) * rstd * g.x + b.x, (u[v].y - mean) * rstd * g.y + b.y,
+                                             (u[v].z - mean) * rstd * g.z + b.z, (u[v].w - mean) * rstd * g.w + b.w);
+                *reinterpret_cast<float4*>(z + base + ch) = o;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
+        }
+        if (amax_out) {          // max |z| as a by-product (one wave per row: only a row that raises the maximum issues the atomic)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+            if (lane == 0 && am > *reinterpret_cast<volatile float*>(amax_out)) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(am));
         }
     } else {
         mean = row_mean[row]; rstd = row_rstd[row];
@@ -419,7 +592,8 @@ int launch_colreduce(Op op, int rows, int c, double* ws, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t glf_bn_workspace(int rows, int c) {
-    return (size_t)2 * MAX_SLICES * (size_t)(c > 0 ? c : 0) + (size_t)2 * (c > 0 ? c : 0);
+    // doubles: 2 x slices x c partial sums, 2 x c finished sums, and (as floats) 2 x slices x c partial maxima of glf_bn_bwd's packed path
+    return (size_t)3 * MAX_SLICES * (size_t)(c > 0 ? c : 0) + (size_t)2 * (c > 0 ? c : 0);
 }
 
 #define REQ_C4(c) GLF_REQUIRE((c) > 0 && ((c) % 4) == 0, GLF_ERR_BAD_SHAPE, "channel count must be a positive multiple of 4 (got %d)", (c))
@@ -482,29 +656,58 @@ extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int 
     return glf::check_launch("bn_apply");
 }
 
+extern "C" int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
+                                      int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                      float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      int relu, float* amax_out, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && y && sums && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply_from_sums: null argument");
+    GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply_from_sums: rows must be > 0");
+    REQ_C4(c); REQ_AL(x, "x"); REQ_AL(y, "y"); REQ_LD(ldx, "ldx"); REQ_LD(ldy, "ldy");
+    GLF_REQUIRE(c <= APPLY_MAX_C, GLF_ERR_UNSUPPORTED, "bn_apply_from_sums: C must be <= %d (use glf_bn_stats_from_sums + glf_bn_apply)", APPLY_MAX_C);
+    GLF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GLF_ERR_NULL, "bn_apply_from_sums: running_mean/var must both be set or both NULL");
+    if (residual) { REQ_AL(residual, "residual"); REQ_LD(ldr, "ldr"); }
+    const long long total4 = (long long)rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_sums_kernel, dim3(stream_grid(total4, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s), x, ldx, residual, ldr, y, ldy, sums, rows, c,
+                       eps, momentum, gamma, beta, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked),
+                       total4, c / 4, relu, amax_out);
+    return glf::check_launch("bn_apply_from_sums");
+}
+
 extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-                          int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s) {
+                          int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
+    GLF_REQUIRE(!packed_dx || amax_out, GLF_ERR_NULL, "bn_bwd: packed_dx needs amax_out (a zeroed device float that receives the bound the image is scaled with)");
     GLF_REQUIRE(!relu || y || beta, GLF_ERR_NULL, "bn_bwd: relu != 0 needs y (the forward output) or beta (to recompute its sign from x)");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_bwd: rows must be > 0");
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
     if (relu && y) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
     const int slices = n_slices_c(rows, c);
-    if (int rc = launch_colreduce(OpBnBwd{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu}, rows, c, workspace, glf::S(s))) return rc;
+    const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu};
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
     float* s_dy = dbeta ? dbeta : sums;
     float* s_dyx = dgamma ? dgamma : sums + c;
-    hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, slices, c, s_dy, s_dyx);
+    if (packed_dx) {
+        float* pmax = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c + (size_t)2 * c);
+        const int c4 = c / 4, tpr = c4 < RT ? c4 : RT;
+        hipLaunchKernelGGL(bnbwd_reduce_kernel, dim3(slices, (c4 + tpr - 1) / tpr), dim3(RT), 0, glf::S(s), op, rows, c, slices, workspace, pmax);
+        if (int rc = glf::check_launch("bn_bwd_reduce")) return rc;
+        hipLaunchKernelGGL(bnbwd_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, pmax, slices, c, gamma, invstd,
+                           1.0f / (float)rows, training, s_dy, s_dyx, amax_out);
+    } else {
+        if (int rc = launch_colreduce(op, rows, c, workspace, glf::S(s))) return rc;
+        hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, slices, c, s_dy, s_dyx);
+    }
     if (int rc = glf::check_launch("bn_bwd_finalize")) return rc;
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
                        Coef{mean, invstd, gamma, beta}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
-                       1.0f / (float)rows, amax_out);
+                       1.0f / (float)rows, amax_out, packed_dx);
     return glf::check_launch("bn_bwd_apply");
 }
 
@@ -521,7 +724,7 @@ extern "C" int glf_colsum(const float* dy, int lddy, float* db, int rows, int c,
 extern "C" int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn_mean, const float* bn_invstd,
                                  const float* bn_gamma, const float* bn_beta, const float* ln_gamma,
                                  const float* ln_beta, float ln_eps, float* z, float* row_mean, float* row_rstd,
-                                 int rows, int c, glf_stream_t s) {
+                                 int rows, int c, float* amax_out, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(w && x && bn_mean && bn_invstd && bn_gamma && bn_beta && ln_gamma && ln_beta && z && row_mean && row_rstd,
                 GLF_ERR_NULL, "bn_res_ln_fwd: null argument");
@@ -530,7 +733,7 @@ extern "C" int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn
     REQ_AL(w, "w"); REQ_AL(x, "x"); REQ_AL(z, "z");
     hipLaunchKernelGGL((bn_res_ln_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, glf::S(s), w, x,
                        Coef{bn_mean, bn_invstd, bn_gamma, bn_beta}, ln_gamma, ln_beta, ln_eps, z, row_mean, row_rstd,
-                       (const float*)nullptr, (float*)nullptr, rows, c);
+                       (const float*)nullptr, (float*)nullptr, rows, c, amax_out);
     return glf::check_launch("bn_res_ln_fwd");
 }
 
@@ -548,7 +751,7 @@ extern "C" int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x
     const Coef bn{bn_mean, bn_invstd, bn_gamma, bn_beta};
     hipLaunchKernelGGL((bn_res_ln_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, glf::S(s), w, x, bn, ln_gamma,
                        (const float*)nullptr, 0.f, (float*)nullptr, const_cast<float*>(row_mean), const_cast<float*>(row_rstd),
-                       dz, du, rows, c);
+                       dz, du, rows, c, (float*)nullptr);
     if (int rc = glf::check_launch("bn_res_ln_bwd")) return rc;
     if (int rc = launch_colreduce(OpLnParam{dz, w, x, bn, row_mean, row_rstd, c}, rows, c, workspace, glf::S(s))) return rc;
     hipLaunchKernelGGL(sum_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, glf::S(s), workspace, n_slices_c(rows, c), c, dln_gamma, dln_beta);

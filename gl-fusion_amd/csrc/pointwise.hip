@@ -618,6 +618,18 @@ extern "C" int glf_dropout(const float* x, float* y, int64_t numel, float p, uin
                        (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step_counter));
     return glf::check_launch("dropout");
 }
+__global__ void amax_combine_kernel(const float* a, const float* b, float scale, int sum, float* out) {
+    const float va = fabsf(*a), vb = b ? fabsf(*b) : 0.f;
+    const float v = scale * (sum ? va + vb : fmaxf(va, vb));
+    if (v > *out) *out = v;
+}
+extern "C" int glf_amax_combine(const float* a, const float* b, float scale, int sum, float* out, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(a && out, GLF_ERR_NULL, "amax_combine: null argument");
+    GLF_REQUIRE(scale >= 0.f, GLF_ERR_BAD_SHAPE, "amax_combine: scale must be >= 0");
+    hipLaunchKernelGGL(amax_combine_kernel, dim3(1), dim3(1), 0, glf::S(s), a, b, scale, sum, out);
+    return glf::check_launch("amax_combine");
+}
 __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
 extern "C" int glf_counter_add(uint64_t* counter, uint64_t inc, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;

@@ -166,8 +166,10 @@ class TpaviFn(Function):
         z = torch.empty_like(x)
         rmu = torch.empty(rows, **f32)
         rrs = torch.empty(rows, **f32)
+        am_z = amax_slot(dev)                      # max|z|: the heads' first convolutions read z (through the global + local sum)
         check(lib.glf_bn_res_ln_fwd(_p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(ln_b), ln_eps,
-                                    _p(z), _p(rmu), _p(rrs), rows, c, _stream()), "bn_res_ln_fwd")
+                                    _p(z), _p(rmu), _p(rrs), rows, c, _p(am_z), _stream()), "bn_res_ln_fwd")
+        set_amax(z, am_z)
         ctx.save_for_backward(x, qkv, att, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g)
         ctx.cfg = (n, L, c, ci, training, mode, tuple(th_w.shape), tuple(wz_w.shape))
         ctx.owners = (wz_w,)                      # parameter owning zW (transposed-copy cache key)
@@ -198,7 +200,7 @@ class TpaviFn(Function):
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), 0, _stream()), "bn_bwd")
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)

@@ -92,7 +92,9 @@ class ASPP(nn.Module):
                 branches.append(conv.forward_nhwc(xi))
             off += ck
         y = ops.conv1x1_cat(self.project[0].weight, branches)
-        return self.project[1].forward_nhwc(y, relu=True)
+        # (the projection's gradient is consumed by ConvCatFn's dgrad / wgrad only -- and only its single-buffer form reads it packed)
+        pg = _CAT_BUFFER and torch.is_grad_enabled() and ops.takes_packed_grad(self.project[0].weight)
+        return self.project[1].forward_nhwc(y, relu=True, packed_grad=pg)
 
     def forward_nhwc(self, x):
         return self.project[3].forward_nhwc(self.trunk_nhwc(x))

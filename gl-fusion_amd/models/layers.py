@@ -43,8 +43,8 @@ class Conv2d(nn.Conv2d):
 
 
 class BatchNorm2d(nn.BatchNorm2d):
-    def forward_nhwc(self, x, relu: bool = False, residual=None, sums=None):
-        return ops.batch_norm_act(x, self, relu, residual, sums)
+    def forward_nhwc(self, x, relu: bool = False, residual=None, sums=None, packed_grad: bool = False):
+        return ops.batch_norm_act(x, self, relu, residual, sums, packed_grad)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
@@ -88,9 +88,12 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
     (sum x, sum x^2 per channel) are accumulated by the conv's own epilogue where the kernel supports it, which saves the
     separate statistics pass over the conv output."""
     training = bn.training or bn.running_mean is None
-    if training and FUSE_BN_STATS and not (conv.in_channels == 1 and conv.kernel_size == (7, 7)):
+    stem = conv.in_channels == 1 and conv.kernel_size == (7, 7)
+    # the conv output's gradient has ONE consumer, this conv's backward: BatchNorm backward may hand it over as a packed image
+    pg = (not stem) and conv.bias is None and torch.is_grad_enabled() and ops.takes_packed_grad(conv.weight)
+    if training and FUSE_BN_STATS and not stem:
         stride, pad, dil = conv._geom()
         if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2]):
             sums = ops.stats_slot(conv.out_channels, x.device)
-            return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums)
-    return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual)
+            return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums, packed_grad=pg)
+    return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual, packed_grad=pg)

@@ -237,10 +237,13 @@ class _WeightRegistry:
         return self.arena[i:i + 1]
 
     def drop(self, key) -> None:
-        im = self.images.pop(key, None)
+        try:
+            im = self.images.pop(key, None)
+        except (AttributeError, TypeError):      # interpreter shutdown: module globals are already gone
+            return
         if im is not None:
             self.dirty = True
-            if im.kind == WJ_AMAX and self.arena is not None and im.amax is not None:
+            if im.kind == 1 and self.arena is not None and im.amax is not None:        # 1 == WJ_AMAX (a literal: see drop at shutdown)
                 self.free.append(int((im.amax.data_ptr() - self.arena.data_ptr()) // 4))
 
     def build(self) -> None:
@@ -309,7 +312,7 @@ def _wimage(owner: torch.Tensor, tag: str, kind: int, src: torch.Tensor, dims, m
         reg.drop(key)
     im = _WImage()
     im.key, im.kind, im.src, im.dims, im.version, im.extra = key, kind, src, tuple(dims), ver, None
-    im.owner = weakref.ref(owner, lambda _r, k=key, d=owner.device: _registry(d).drop(k))
+    im.owner = weakref.ref(owner, lambda _r, k=key, r=reg: r.drop(k))
     im.amax = reg.slot() if kind == WJ_AMAX else amax
     im.dst = make_dst() if make_dst is not None else None
     reg.images[key] = im
@@ -401,6 +404,27 @@ def stats_slot(c: int, dev) -> torch.Tensor:
     i = pool[1]
     pool[1] = i + need
     return pool[0][i:i + need].view(2, c)
+
+
+def amax_bound(t: torch.Tensor, srcs: Sequence[Optional[torch.Tensor]], scale: float = 1.0, sum_: bool = False) -> None:
+    """Attach to t an upper bound of its maximum derived from the maxima of the tensors it was made from (glf_amax_combine: one
+    tiny launch per pair, no pass over the data): scale * max(srcs) or scale * sum(srcs).  Does nothing unless every source's
+    maximum is known (t is then measured on first use, as before)."""
+    if _PREC[0] < 2:
+        return
+    ams = [getattr(x, "_glf_amax", None) for x in srcs]
+    ams = [h[2] if (h is not None and h[0] == x._version and h[1] == x.data_ptr()) else None for h, x in zip(ams, srcs)]
+    if not ams or any(a is None for a in ams):
+        return
+    out = amax_slot(t.device)
+    if sum_:
+        if len(ams) != 2:
+            raise ValueError("amax_bound: sum_ takes exactly two sources")
+        check(lib.glf_amax_combine(_p(ams[0]), _p(ams[1]), float(scale), 1, _p(out), _stream()), "amax_combine")
+    else:
+        for i in range(0, len(ams), 2):
+            check(lib.glf_amax_combine(_p(ams[i]), _p(ams[i + 1]) if i + 1 < len(ams) else None, float(scale), 0, _p(out), _stream()), "amax_combine")
+    set_amax(t, out)
 
 
 def set_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> None:
@@ -763,6 +787,9 @@ class Conv2dFn(Function):
         rows_o = n * ho * wo
         dx = dw = db = None
         am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
+        dy_pk = packed_only(dy)              # BatchNorm backward wrote the gradient as a packed pre-split image (no fp32 form exists)
+        if dy_pk and (has_bias or am_dy is None or not (split_mode() and cout % 32 == 0)):
+            raise RuntimeError("glfusion_amd: a packed-only gradient reached a convolution that cannot consume it")
         def dgrad():
             dx = None
             if True:
@@ -791,7 +818,7 @@ class Conv2dFn(Function):
                         wT = tap_major_T(ctx.weight_ref)
                         ok = nt_presplit_ok(cout, cout, cout)
                         ok_dy = ok and cin * bin(mask).count("1") >= PRESPLIT_MIN_COLS
-                        da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
+                        da, pa = (dy, True) if dy_pk else pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
                         wb, pb = pick(wT, weight_packed(wT, ctx.weight_ref, "wT", am_w) if ok else None, ok)
                         gemm("nt", da, wb, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin,
                              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 2,
@@ -823,7 +850,7 @@ class Conv2dFn(Function):
                 am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
                 # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
                 ok_dy = ok and (packed_hit(dy, am_dy) is not None or cin * ntap >= PRESPLIT_MIN_COLS)
-                da, pa = pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
+                da, pa = (dy, True) if dy_pk else pick(dy, act_packed(dy, am_dy, True) if ok_dy else None, ok_dy)
                 xb, pb = pick(x, ctx.x_packed[0] if ctx.x_packed is not None else None, ok)
                 gemm("tn", da, xb, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask,
                      tap_stride_b=cout * cin, gather=0 if plain else 1,
@@ -839,7 +866,7 @@ class Conv2dFn(Function):
         if WGRAD_STREAM and STREAMS and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             # dgrad and wgrad of one conv are independent and read the same dy: the weight gradient goes to a side stream of
             # the stream this node runs on (its workgroups fill the partial last round of the dgrad kernel and vice versa)
-            if presplit_ok(dy, am_dy) and (cin * taps >= PRESPLIT_MIN_COLS):
+            if not dy_pk and presplit_ok(dy, am_dy) and (cin * taps >= PRESPLIT_MIN_COLS):
                 act_packed(dy, am_dy, True)                  # the shared image is made before the fork, on this stream
             cur = torch.cuda.current_stream()
             side = _wgrad_streams.get(cur.cuda_stream)
@@ -947,6 +974,9 @@ class ConvCatFn(Function):
         grads = []
         off = 0
         am_dy, am_w = amax_of(dy), amax_of(ctx.weight_ref)
+        dy_pk = packed_only(dy)
+        if dy_pk and (not ctx.cat or ctx.has_bias or am_dy is None or not (split_mode() and cout % 32 == 0)):
+            raise RuntimeError("glfusion_amd: a packed-only gradient reached a projection that cannot consume it")
         if ctx.cat:
             t0 = xs[0]
             if any(ctx.needs_input_grad[2:]):
@@ -955,7 +985,7 @@ class ConvCatFn(Function):
                 if split_mode() and cout % 32 == 0:
                     w2T = weight_T(w2, ctx.weight_ref)
                     ok = nt_presplit_ok(cout, cout, cout)
-                    da, pa = pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
+                    da, pa = (dy, True) if dy_pk else pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
                     wb, pb = pick(w2T, weight_packed(w2T, ctx.weight_ref, "T2", am_w) if ok else None, ok)
                     gemm("nt", da, wb, dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot,
                          amax_a=am_dy, amax_b=am_w, amax_c=am_dc, a_packed=pa, b_packed=pb)
@@ -974,7 +1004,7 @@ class ConvCatFn(Function):
                 if tn_needs_zero(split):
                     zero_(dw)
                 ok = tn_presplit_ok(cout, ctot, cout, ctot)
-                da, pa = pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
+                da, pa = (dy, True) if dy_pk else pick(dy, act_packed(dy, am_dy, True) if ok else None, ok)
                 gemm("tn", da, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=split,
                      amax_a=am_dy, amax_b=amax_of(t0), a_packed=pa)
             return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
@@ -1086,12 +1116,13 @@ def _rows_view(t: torch.Tensor):
 # BatchNorm (+ residual, + ReLU)
 # ----------------------------------------------------------------------------------------
 _last_bn = [None]          # (mean, invstd, rows) of the most recent BatchNormActFn.forward (read by BN_TAP)
+FUSE_BN_FINALIZE = os.environ.get("GLF_FUSE_BN_FINALIZE", "1") != "0"     # statistics finished inside the apply kernel
 
 
 class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool,
-                momentum: float, eps: float, relu: bool, sums=None):
+                momentum: float, eps: float, relu: bool, sums=None, packed_grad: bool = False):
         _chk(x, "bn input"); _chk(gamma, "bn weight"); _chk(beta, "bn bias")
         x = _contig(x)
         c = x.shape[-1]
@@ -1099,7 +1130,10 @@ class BatchNormActFn(Function):
         dev = x.device
         mean = torch.empty(c, dtype=torch.float32, device=dev)
         invstd = torch.empty(c, dtype=torch.float32, device=dev)
-        if training and sums is not None:        # (sum x, sum x^2) came out of the producing contraction's epilogue
+        fused_stats = training and sums is not None and c <= 4096 and FUSE_BN_FINALIZE
+        if fused_stats:
+            pass                                 # finished inside the apply kernel below (one launch)
+        elif training and sums is not None:      # (sum x, sum x^2) came out of the producing contraction's epilogue
             check(lib.glf_bn_stats_from_sums(_p(sums), rows, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
                                              _p(running_var), _p(nbt), _stream()), "bn_stats_from_sums")
         elif training:
@@ -1113,12 +1147,18 @@ class BatchNormActFn(Function):
             residual = _contig(_chk(residual, "bn residual"))
         y, ldy, shared = _take_out(x.shape, dev)
         am = shared if shared is not None else amax_slot(dev)
-        check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
-                               int(relu), _p(am), _stream()), "bn_apply")
+        if fused_stats:
+            check(lib.glf_bn_apply_from_sums(_p(x), c, _p(residual), c, _p(y), ldy, _p(sums), rows, c, eps, momentum, _p(gamma), _p(beta),
+                                             _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), int(relu), _p(am),
+                                             _stream()), "bn_apply_from_sums")
+        else:
+            check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
+                                   int(relu), _p(am), _stream()), "bn_apply")
         set_amax(y, am)
         # without a residual the ReLU mask is recomputed from x in backward (sign of the same expression): y is not kept
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, gamma, beta if relu else None)
         ctx.cfg = (rows, c, relu, training, residual is not None, ldy)
+        ctx.packed_grad = bool(packed_grad) and _PREC[0] >= 2
         ctx.join = getattr(residual, "_glf_join", None) if residual is not None else None
         _last_bn[0] = (mean, invstd, rows)
         return y
@@ -1135,12 +1175,19 @@ class BatchNormActFn(Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
         am = amax_slot(dev)
+        # packed: the producing conv reads this gradient only through its dgrad / wgrad contractions -- write it ONCE, as the
+        # packed pre-split image they want (scaled by a bound of its maximum the reduction pass provides), instead of fp32
+        # followed by a split pass
+        packed = ctx.packed_grad and _PREC[0] >= 2 and am is not None and PACKED_GRADS
         check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
-                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), _stream()), "bn_bwd")
+                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), int(packed),
+                             _stream()), "bn_bwd")
         set_amax(dx, am)
+        if packed:
+            dx._glf_packed_only = True
         if ctx.join is not None and dres is not None:
             ctx.join.parked, dres = dres, None       # handed to the block's first conv, whose dgrad accumulates onto it
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 # When a list, every train-mode batch_norm_act call appends (module, batch mean, batch invstd, rows): enough to
@@ -1158,7 +1205,24 @@ def replay_bn_updates(records) -> None:
                                         _p(bn.running_mean), _p(bn.running_var), _p(bn.num_batches_tracked), _stream()), "bn_replay_running")
 
 
-def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None):
+# BatchNorm backward hands the gradient of a conv output to that conv as a packed pre-split image (no fp32 copy, no split pass)
+PACKED_GRADS = os.environ.get("GLF_PACKED_GRADS", "1") != "0"
+
+
+def takes_packed_grad(weight: torch.Tensor) -> bool:
+    """True when Conv2dFn / ConvCatFn backward can consume the gradient of a conv's output as a packed-only image: both its
+    dgrad (NT, K = Cout) and its weight gradient (TN, M = Cout, N = Cin) run on the aligned split-fp16 kernels."""
+    if not PACKED_GRADS or _PREC[0] < 2 or not PRESPLIT:
+        return False
+    cout, cin = weight.shape[0], weight.shape[1]
+    return cout % 32 == 0 and nt_presplit_ok(cout, cout, cout) and tn_presplit_ok(cout, cin, cout, cin)
+
+
+def packed_only(t: torch.Tensor) -> bool:
+    return bool(getattr(t, "_glf_packed_only", False))
+
+
+def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None, packed_grad: bool = False):
     """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
     optionally fused with a residual add and ReLU."""
     training = bn.training or bn.running_mean is None
@@ -1173,7 +1237,7 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
                              bn.running_mean if (track or not training) else None,
                              bn.running_var if (track or not training) else None,
                              bn.num_batches_tracked if track else None,
-                             training, momentum, float(bn.eps), relu, sums if training else None)
+                             training, momentum, float(bn.eps), relu, sums if training else None, packed_grad)
     if BN_TAP is not None and track:
         BN_TAP.append((bn,) + _last_bn[0])
     return y
@@ -1211,6 +1275,7 @@ class DropoutFn(Function):
         x = _contig(_chk(x, "dropout input"))
         y = torch.empty_like(x)
         check(lib.glf_dropout(_p(x), _p(y), x.numel(), p, seed, _p(step_counter(x.device)), _stream()), "dropout")
+        amax_bound(y, [x], scale=1.0 / (1.0 - p))          # kept elements are scaled by 1 / (1 - p)
         ctx.cfg = (p, seed)
         return y
 
@@ -1242,6 +1307,7 @@ class MaxPool3x3s2Fn(Function):
         y = torch.empty(n, ho, wo, c, dtype=torch.float32, device=x.device)
         idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=x.device)
         check(lib.glf_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()), "maxpool_fwd")
+        amax_bound(y, [x])                                  # a window maximum never exceeds the input's largest magnitude
         ctx.save_for_backward(idx)
         ctx.cfg = (n, h, w, c)
         return y
@@ -1504,6 +1570,7 @@ def _gate_forward(ctx, cls, ctr, f, weight: float):
     a = torch.empty(rows, dtype=torch.float32, device=f.device)
     am = torch.empty(rows, dtype=torch.int32, device=f.device)
     check(lib.glf_gate_fwd(_p(cls), ncls, _p(ctr), _p(f), _p(y), _p(a), _p(am), weight, rows, c, _stream()), "gate_fwd")
+    amax_bound(y, [f])                                      # y = f * a with a in (0, 1)
     ctx.save_for_backward(cls, ctr, f, a, am)
     ctx.cfg = (rows, c, ncls, weight)
     return y, a
@@ -1602,6 +1669,7 @@ class StackViewsFn(Function):
         inner = h * w * c
         for i, t in enumerate(xs):
             check(lib.glf_copy_frames(_p(t), inner, _p(out[:, i]), v * inner, n, inner, _stream()), "stack_views")
+        amax_bound(out, xs)
         ctx.cfg = (n, v, h, w, c)
         return out
 
@@ -1636,6 +1704,7 @@ class AddViewsFn(Function):
         for i in range(v):
             out = torch.empty(n, h, w, c, dtype=torch.float32, device=g.device)
             check(lib.glf_add_frames(_p(g[:, i]), v * inner, _p(l[:, i]), v * inner, _p(out), inner, n, inner, _stream()), "add_views")
+            amax_bound(out, [g, l], sum_=True)
             outs.append(out)
         ctx.cfg = (n, v, h, w, c)
         return tuple(outs)

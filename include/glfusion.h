@@ -319,16 +319,30 @@ int glf_bn_eval_coeffs(const float* running_mean, const float* running_var, floa
 int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                  const float* mean, const float* invstd, const float* gamma, const float* beta,
                  int rows, int c, int relu, float* amax_out, glf_stream_t s);
+/* glf_bn_stats_from_sums + glf_bn_apply in ONE launch (train mode, statistics from a contraction's colstats): every
+ * workgroup finishes mean / invstd for all channels in LDS, workgroup 0 writes them to mean / invstd (for the backward pass)
+ * and updates running_mean / running_var / num_batches_tracked (all three may be NULL).  Bit-identical to the two calls.
+ * C <= 4096. */
+int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
+                           int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
+                           float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           int relu, float* amax_out, glf_stream_t s);
 /* Backward.  y is the forward output (ReLU mask = y > 0); it may be NULL when relu == 0, and also when
  * relu != 0 and there was NO residual: the mask is then recomputed from x with beta (one tensor read less
  * in both passes; with a residual the sign of y depends on it, so y is required).
  * training != 0: full batch-stat backward; training == 0: dx = dy*mask*gamma*invstd.
  * dres (may be NULL) receives dy*mask (gradient of the residual input).  amax_out: as in
- * glf_bn_apply, for dx. */
+ * glf_bn_apply, for dx.
+ * packed_dx != 0 (precision 3 / 4 callers): dx is NOT written as fp32 but directly as the packed pre-split image of
+ * glf_split_f16_packed -- what the producing convolution's dgrad and wgrad read (glf_gemm_params.a_presplit) -- so the
+ * gradient of a conv output exists once, in the form its consumers want, and the separate split pass (one read + one write
+ * of the tensor) is gone.  The image's power-of-two scale must be known before the first element is written: the reduction
+ * pass also takes max|dy'| and max|xhat| per channel, and *amax_out (required, zeroed by the caller) receives the upper
+ * bound of max|dx| derived from them (typically within 2x of the true maximum); pass the same scalar as amax_a. */
 int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                const float* mean, const float* invstd, const float* gamma, const float* beta /* may be NULL with y */,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-               int rows, int c, int relu, int training, double* workspace, float* amax_out, glf_stream_t s);
+               int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise pieces of the path.
@@ -354,6 +368,11 @@ int glf_relu_bwd(const float* dy, const float* y, float* dx, int64_t numel, glf_
  * a hipGraph replays with the same `seed` argument, the counter -- advanced once per training step by glf_counter_add, itself
  * part of the graph -- gives every replay its own masks (deeplabv3.py:159 Dropout(0.5), a fresh mask per forward). */
 int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed, const uint64_t* step_counter, glf_stream_t s);
+/* Operand-maximum bookkeeping for tensors whose maximum follows from their sources' (no pass over the data):
+ * *out = max(*out, scale * (sum ? |*a| + |*b| : max(|*a|, |*b|))); b may be NULL.  A dropout output is bounded by its input's
+ * maximum / (1 - p), a sum of two tensors by the sum of their maxima, a stack of tensors by the largest.  Upper bounds are
+ * what glf_gemm_params.amax_a / amax_b ask for. */
+int glf_amax_combine(const float* a, const float* b, float scale, int sum, float* out, glf_stream_t s);
 /* *counter += inc (a device uint64), stream-ordered. */
 int glf_counter_add(uint64_t* counter, uint64_t inc, glf_stream_t s);
 /* Local gate (a5, ours.py:1802-1816): a[r] = sigmoid(w * max_c sigmoid(cls[r][c]) * sigmoid(ctr[r])),
@@ -375,11 +394,12 @@ int glf_add_frames(const float* a, int64_t a_fs, const float* b, int64_t b_fs, f
  * tensor that feeds several branches (f4 -> classifier / centerness / gate / fusion; ASPP input -> 5 branches). */
 int glf_add_n(const float* const* inputs, int k, float* out, int64_t numel, glf_stream_t s);
 /* W_z tail of TPAVIModule (ours.py:908-915): z = LayerNorm_C( BN(w) + x ) with the BN already
- * folded into per-channel (bn_mean, bn_invstd, gamma, beta).  Saves row mean / rstd. */
+ * folded into per-channel (bn_mean, bn_invstd, gamma, beta).  Saves row mean / rstd.  amax_out (may be NULL): as in
+ * glf_bn_apply, receives max(*amax_out, max|z|). */
 int glf_bn_res_ln_fwd(const float* w, const float* x, const float* bn_mean, const float* bn_invstd,
                       const float* bn_gamma, const float* bn_beta, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, float* z, float* row_mean, float* row_rstd,
-                      int rows, int c, glf_stream_t s);
+                      int rows, int c, float* amax_out, glf_stream_t s);
 /* LayerNorm backward: du (gradient w.r.t. u = BN(w)+x), dgamma/dbeta of the LayerNorm.
  * workspace: glf_bn_workspace(rows, c) doubles. */
 int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x, const float* bn_mean,

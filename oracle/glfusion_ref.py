@@ -10,13 +10,18 @@ Pinning status
 * a1, a2 (conv1 swap), a4, a5, a6, a7, a9, a10: PINNED by tests/golden/*.npz, which
   were generated in the build container by importing the reference's own
   ``models/ours.py`` (tests/golden/make_golden.py) and executing it on CPU.
-* a3 (ResNet-50 Bottleneck arithmetic): PARITY UNPINNED.  The reference takes it from
-  torchvision==0.9.1 (requirements.txt:25; call site models/segmentation.py:205-207),
-  which is neither vendored under /root/reference nor installed here.  ``ResNet50Trunk``
-  below restates the published v1.5 architecture; the only in-tree structural evidence
-  is models/resnet.py:43-79 (same block, no dilation) and the shape comments in
-  models/_utils.py:214-217.  The golden generator plugs this same class in as the
-  torchvision stand-in, so the fixtures pin the wiring around it, not its arithmetic.
+* a3 (ResNet-50): the BLOCK is pinned -- tests/golden/bottleneck_ref.npz comes from the reference's own in-tree Bottleneck
+  (models/resnet.py:43-79, the block torchvision's ResNet-50 is made of; identity and stride-2 + downsample forms, train
+  forward / gradients / running statistics / eval forward, fp32 and fp64) and ``Bottleneck`` below matches it to 1e-6.
+  STILL UNPINNED: torchvision's dilation rule of ``_make_layer`` (block 0 of a dilated stage keeps the previous dilation,
+  padding = dilation).  The reference takes the trunk from torchvision==0.9.1 (requirements.txt:25; call site
+  models/segmentation.py:205-207), which is neither vendored under /root/reference nor installed here, and the in-tree block
+  has no dilation argument; ``ResNet50Trunk`` restates the published v0.9.1 rule.  The golden generator plugs this same
+  class in as the torchvision stand-in, so the end-to-end fixtures pin the wiring around the trunk, not that rule.
+* f3: all eight fixture-able variants (incl. model19, Global_and_Local_CPS) are checked against fixtures of the reference's
+  own classes on the CPU side (tests/test_oracle_golden.py).
+* f4 (prepare_clip): PARITY UNPINNED -- monai / nibabel are absent; the transform chain is restated from
+  datasets/loader.py:460-498.
 
 All file:line citations are relative to /root/reference/GLfusion/.
 """

@@ -26,7 +26,7 @@ def test_header_parses_and_library_exports_every_symbol():
     # pure host-side queries work without a GPU
     dll.glf_bn_workspace.restype = ctypes.c_size_t
     dll.glf_bn_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
-    assert dll.glf_bn_workspace(50176, 2048) == 2 * 1024 * 2048 + 2 * 2048
+    assert dll.glf_bn_workspace(50176, 2048) == 3 * 1024 * 2048 + 2 * 2048
 
 
 def test_gemm_params_struct_matches_header_layout():

@@ -463,45 +463,87 @@ def test_variants_eval_vs_golden(golden_dir, name, precision):
             assert close(_sample(third), torch.from_numpy(g[f"third:{v}"]), 1e-3), v
 
 
+def _oracle_grads_64_and_32(ref, loss_of):
+    """Gradients of the oracle's float64 evaluation, and the relative L2 deviation of its OWN float32 evaluation from them
+    per tensor (what any fp32 arithmetic is entitled to on that tensor)."""
+    import copy
+    r32 = copy.deepcopy(ref).float().train()
+    loss_of(r32, torch.float32).backward()
+    r64 = ref.double().train()
+    want = loss_of(r64, torch.float64)
+    want.backward()
+    g64 = {k: p.grad for k, p in r64.named_parameters() if p.grad is not None}
+    noise = {}
+    for k, p in r32.named_parameters():
+        if k in g64:
+            noise[k] = float((p.grad.double() - g64[k]).norm()) / max(float(g64[k].norm()), 1e-30)
+    return float(want.detach()), g64, noise, r64
+
+
+def _gate_all_gradients(model, gref, noise32, label, base=2e-3):
+    """Every parameter gradient against the oracle's float64 evaluation: relative L2 <= base, or 10x the oracle's own
+    fp32-vs-fp64 deviation on that tensor where that is larger (the rule of test_e2e_train_kinkfree_gradients: BatchNorm over
+    the N per-frame averages of an ASPP pooled branch, or the stem's weights in front of a BatchNorm, are ill-conditioned for
+    ANY fp32 arithmetic), + a floor of 2e-5 of the largest gradient norm in the parameter's top-level module (a bias in front
+    of a train-mode BatchNorm has a structurally zero gradient)."""
+    scale = {}
+    for k, w in gref.items():
+        scale[k.split(".")[0]] = max(scale.get(k.split(".")[0], 0.0), float(w.norm()))
+    worst = (0.0, "", 0.0)
+    n_loose = 0
+    for k, p in model.named_parameters():
+        if k not in gref:
+            continue
+        want = gref[k].double()
+        err = float((p.grad.double().cpu() - want).norm())
+        rel_tol = max(base, 10.0 * noise32.get(k, 0.0))
+        n_loose += rel_tol > base
+        tol = rel_tol * float(want.norm()) + 2e-5 * scale[k.split(".")[0]]
+        if err / tol > worst[0]:
+            worst = (err / tol, k, err / max(float(want.norm()), 1e-30))
+        assert err <= tol, (label, k, err, float(want.norm()), tol, noise32.get(k))
+    print(f"{label}: closest to its gate: {worst[1]} at {worst[0]:.2f} of the tolerance (relative L2 {worst[2]:.2e}); "
+          f"{n_loose} of {len(gref)} tensors held to 10x the oracle's own fp32 deviation instead of {base:g}")
+
+
 @pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_conv_merge", "Foreground_and_Background", "model19", "Global_and_Local_CPS"])
 def test_variants_train_step_vs_oracle(name):
+    """Train step of every variant on the kink-free fill (no ReLU input near zero: gradients are smooth in the arithmetic, see
+    oracle.kinkfree_fill): loss to 2e-6, EVERY parameter gradient to 2e-3 relative L2 of the oracle's."""
     import glfusion_amd.models as M
     from glfusion_amd import ops
-    views, n = ["1", "3"], 4
+    views, n = ["1", "3"], 3
     ref = getattr(orc, name)(views)
-    orc.closed_form_fill(ref, salt=6)
+    orc.kinkfree_fill(ref, salt=6)
     orc.set_dropout(ref, 0.0)
     model = getattr(M, name)(views)
     model.load_state_dict(ref.state_dict(), strict=True)
     orc.set_dropout(model, 0.0)
     model = model.to(DEV).train()
-    ref.train()
-    imgs = orc.closed_form_images(views, n, 112, 112)
+    imgs = orc.varied_images(views, n)
     tgts = orc.closed_form_targets(views, n)
     heads = (0, 1) if name == "Global_and_Local_CPS" else (0,)      # CPS: both networks' masks are supervised
-    out_ref = ref(imgs)
-    want = sum(torch.nn.functional.binary_cross_entropy_with_logits(out_ref[h][v], tgts[v], reduction="sum") for h in heads for v in views)
-    want.backward()
-    out = model({v: t.to(DEV) for v, t in imgs.items()})
-    got = sum(ops.bce_with_logits_sum(out[h][v], tgts[v].to(DEV)) for h in heads for v in views)
-    got.backward()
-    assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))
-    gref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    def loss_of(net, dt):
+        o = net({v: t.to(dt) for v, t in imgs.items()})
+        return sum(torch.nn.functional.binary_cross_entropy_with_logits(o[h][v], tgts[v].to(dt), reduction="sum") for h in heads for v in views)
+    want, gref, noise32, ref = _oracle_grads_64_and_32(ref, loss_of)
+    ops.set_precision("f16x3")                                # the bench's arithmetic
+    try:
+        out = model({v: t.to(DEV) for v, t in imgs.items()})
+        got = sum(ops.bce_with_logits_sum(out[h][v], tgts[v].to(DEV)) for h in heads for v in views)
+        got.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("f32")
+    assert abs(float(got) - want) <= 2e-6 * abs(want)
     have = {k for k, p in model.named_parameters() if p.grad is not None}
     assert have == set(gref)                                  # e.g. Global_only: no gradient reaches the centerness heads
-    attn = {"Local_only": "local_attn", "Global_and_Local_conv_merge": "merge", "model19": "non_local",
-            "Global_and_Local_CPS": "global_attn_2"}.get(name, "global_attn")
-    top = max(float(w.norm()) for k, w in gref.items() if k.startswith(attn))
-    for k, p in model.named_parameters():
-        if k.startswith(attn) and k in gref:
-            assert float((p.grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm()) + 1e-3 * top, k
+    _gate_all_gradients(model, gref, noise32, name)
     if name == "Global_and_Local_CPS":
-        # network 2's encoder is the template shared by both views: its gradient is the sum over the views
-        k = "network.backbone.layer4.2.conv3.weight"
-        assert float((dict(model.named_parameters())[k].grad.double().cpu() - gref[k].double()).norm()) <= 2e-2 * float(gref[k].norm())
+        # network 2's encoder is the template shared by both views: one running-statistics update per view
         sd, sd_ref = model.state_dict(), ref.state_dict()
         for b in ("network.backbone.bn1.running_mean", "network.backbone.layer4.2.bn3.running_var", "network.backbone.bn1.num_batches_tracked"):
-            assert close(sd[b].float(), sd_ref[b].float(), 1e-4), b          # one update per view of the shared BatchNorm layers
+            assert close(sd[b].float(), sd_ref[b].float(), 1e-4), b
 
 
 def test_temporal_variant_vs_oracle():
@@ -542,11 +584,40 @@ def test_temporal_variant_vs_oracle():
     pred = model(dimgs, is_video=True)[0]
     lg = sum(ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
     lg.backward()
-    assert abs(float(lg) - float(lw)) <= 2e-5 * abs(float(lw))
-    gw = ref.global_attn.g.weight.grad.double()
-    gg = model.global_attn.g.weight.grad.double().cpu()
     _ops.set_precision("f32")
-    assert float((gg - gw).norm()) <= 3e-2 * float(gw.norm())          # fp32 gradient noise of this network: see test_gpu_engine
+    assert abs(float(lg) - float(lw)) <= 2e-5 * abs(float(lw))
+    # (the eval-parity half above pins the fixture's closed-form fill; the gradient half runs on the kink-free fill below)
+
+
+def test_temporal_variant_train_step_kinkfree():
+    """is_video train step on the kink-free fill: every parameter gradient within 2e-3 relative L2 of the oracle's spelled-out
+    version of the temporal branch (L = T V h w positions attend to each other)."""
+    import glfusion_amd.models as M
+    from glfusion_amd import ops as _ops
+    _ops.set_precision("f16x3")
+    try:
+        views, n = ["1", "3"], 3
+        ref = orc.Global_and_Local_Temporal(views)
+        orc.kinkfree_fill(ref, salt=8)
+        orc.set_dropout(ref, 0.0)
+        model = M.Global_and_Local_Temporal(views)
+        model.load_state_dict(ref.state_dict(), strict=True)
+        orc.set_dropout(model, 0.0)
+        model = model.to(DEV).train()
+        imgs, tgts = orc.varied_images(views, n), orc.closed_form_targets(views, n)
+
+        def loss_of(net, dt):
+            o = net({v: t.to(dt) for v, t in imgs.items()}, True)
+            return sum(torch.nn.functional.binary_cross_entropy_with_logits(o[0][v], tgts[v].to(dt), reduction="sum") for v in views)
+        lw, gref, noise32, ref = _oracle_grads_64_and_32(ref, loss_of)
+        pred = model({v: t.to(DEV) for v, t in imgs.items()}, is_video=True)[0]
+        lg = sum(_ops.bce_with_logits_sum(pred[v], tgts[v].to(DEV)) for v in views)
+        lg.backward()
+        assert abs(float(lg) - lw) <= 2e-6 * abs(lw)
+        assert {k for k, p in model.named_parameters() if p.grad is not None} == set(gref)
+        _gate_all_gradients(model, gref, noise32, "Global_and_Local_Temporal(is_video)")
+    finally:
+        _ops.set_precision("f32")
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -473,6 +473,7 @@ def test_presplit_images_are_not_retained_when_memory_is_short():
         for frac in (keep[0], 0.0):
             _ops.PRESPLIT_OFF_FRAC = frac
             _ops._retain_off.clear()
+            _ops.begin_step()                       # the retention decision is taken once per step
             xd, wd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
             y = _ops.conv2d(xd, wd, None, 1, 0, 1)
             retained = getattr(xd, "_glf_packed", None) is not None
@@ -484,6 +485,7 @@ def test_presplit_images_are_not_retained_when_memory_is_short():
         _ops.PRESPLIT_OFF_FRAC = keep[0]
         _ops._retain_off.clear()
         _ops._retain_off.update(keep[1])
+        _ops.begin_step()
         _ops.set_precision("f32")
     for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
         assert torch.equal(a, b), f"{name} changed with retention off: {(a - b).abs().max().item():.3e}"
@@ -514,6 +516,98 @@ def test_split_f16_packed_layout_and_errors():
         assert lib.glf_split_f16_packed(x.data_ptr(), 37, 64, 62, am.data_ptr(), pk.data_ptr(), 64, None) != 0
         assert lib.glf_split_f16_packed(None, 37, 64, 64, am.data_ptr(), pk.data_ptr(), 64, None) != 0
     finally:
+        _ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("relu,res,training", [(True, False, True), (True, True, True), (False, False, True), (True, False, False)])
+@pytest.mark.parametrize("shape", [(3, 9, 11, 64), (2, 7, 5, 2048)])
+def test_bn_backward_writes_packed_gradient(relu, res, training, shape):
+    """glf_bn_bwd(packed_dx = 1): dx comes out as the packed pre-split fp16 image, scaled by an UPPER BOUND of max|dx| that the
+    reduction pass derives (max|dy'|, max|xhat|, the two sums per channel).  Checks: the bound is a bound and is tight (< 4x);
+    the image reconstructs the fp32 dx to 2^-21 of the bound; dgamma / dbeta / dres are those of the fp32 path."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd._lib import lib, check
+    _ops.set_precision("f16x3")
+    try:
+        c = shape[-1]
+        rows = int(np.prod(shape[:-1]))
+        x = (rnd(*shape, seed=81) * 2 + 0.4).to(DEV)
+        dy = (rnd(*shape, seed=82) * 3.0).to(DEV)
+        gamma, beta = rnd(c, seed=83, lo=0.5, hi=1.5).to(DEV), rnd(c, seed=84).to(DEV)
+        mean, invstd = x.view(rows, c).mean(0).contiguous(), (1.0 / (x.view(rows, c).var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+        r = rnd(*shape, seed=85).to(DEV) if res else None
+        y = (x - mean) * invstd * gamma + beta
+        if res:
+            y = y + r
+        y = torch.relu(y).contiguous() if relu else y.contiguous()
+        outs = []
+        for packed in (0, 1):
+            dx, dres = torch.empty_like(x), (torch.empty_like(x) if res else None)
+            dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+            am = torch.zeros(1, device=DEV)
+            ws = torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=DEV)
+            p = lambda t: None if t is None else t.data_ptr()
+            check(lib.glf_bn_bwd(p(dy), c, p(x), c, p(y) if (relu and res) else None, c, p(mean), p(invstd), p(gamma), p(beta), p(dx), c,
+                                 p(dres), c, p(dg), p(db), rows, c, int(relu), int(training), p(ws), p(am), packed, None), "bn_bwd")
+            torch.cuda.synchronize()
+            outs.append((dx, dres, dg, db, float(am)))
+        (dx0, dres0, dg0, db0, am0), (pk, dres1, dg1, db1, bound) = outs
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+        if res:
+            assert torch.equal(dres0, dres1)
+        true_max = float(dx0.abs().max())
+        assert abs(am0 - true_max) <= 1e-6 * true_max
+        assert true_max <= bound <= 4.0 * true_max, (true_max, bound)
+        # reconstruct with the library's scale: the power of two that brings the bound into [2^13, 2^14)
+        e = int(np.floor(np.log2(bound)))
+        s = 2.0 ** (13 - e)
+        halves = pk.view(torch.float16).view(rows, c // 4, 8).double().cpu()
+        recon = ((halves[..., :4] + halves[..., 4:] * 2.0 ** -11) / s).reshape(rows, c)
+        err = float((recon - dx0.view(rows, c).double().cpu()).abs().max())
+        assert err <= 2.0 ** -21 * bound, (err, bound)
+    finally:
+        _ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 1, 1, 1), (2, 14, 14, 128, 256, 1, 1, 0, 1), (1, 28, 28, 256, 256, 3, 1, 12, 12),
+                                 (2, 15, 15, 64, 128, 3, 2, 1, 1)])
+def test_conv_bn_backward_with_packed_gradient_matches_fp32_gradient_path(cfg):
+    """conv -> BatchNorm(train) -> ReLU with the BatchNorm gradient handed to the conv as a packed-only image (the default)
+    against the same chain with GLF_PACKED_GRADS off (fp32 gradient + split pass): input / weight / BN gradients agree to
+    fp32-noise level (the two differ only in the power-of-two scale of one operand)."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd.models.layers import BatchNorm2d, Conv2d, conv_bn_act
+    n, h, w, cin, cout, k, stride, pad, dil = cfg
+    _ops.set_precision("f16x3")
+    try:
+        conv = Conv2d(cin, cout, k, stride=stride, padding=pad, dilation=dil, bias=False)
+        bn = BatchNorm2d(cout)
+        with torch.no_grad():
+            conv.weight.copy_(rnd(*conv.weight.shape, seed=91) * 0.2)
+            bn.weight.copy_(rnd(cout, seed=92, lo=0.5, hi=1.5)); bn.bias.copy_(rnd(cout, seed=93))
+        conv, bn = conv.to(DEV), bn.to(DEV).train()
+        x0 = rnd(n, h, w, cin, seed=94)
+        res = []
+        saw_packed = []
+        for flag in (True, False):
+            _ops.PACKED_GRADS = flag
+            for p in list(conv.parameters()) + list(bn.parameters()):
+                p.grad = None
+            x = x0.to(DEV).requires_grad_(True)
+            y = conv_bn_act(x, conv, bn, relu=True)
+            gy = rnd(*y.shape, seed=95).to(DEV)
+            seen = []
+            hook = y.grad_fn.next_functions[0][0].register_prehook(lambda g: seen.append(_ops.packed_only(g[0]))) if flag else None
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append((x.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+            saw_packed.append(seen)
+        assert saw_packed[0] == [True], "the conv did not receive a packed-only gradient"
+        for a, b, name in zip(res[0], res[1], ("dx", "dw", "dgamma", "dbeta")):
+            err = float((a - b).norm() / (b.norm() + 1e-30))
+            assert err <= 2e-6, (name, err)
+    finally:
+        _ops.PACKED_GRADS = True
         _ops.set_precision("f32")
 
 

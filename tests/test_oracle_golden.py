@@ -153,7 +153,8 @@ def test_oracle_cycle_losses_match_reference_fixture(golden_dir):
             assert float((f.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background"])
+@pytest.mark.parametrize("name", ["Global_only", "Local_only", "Global_and_Local_cyc_nofusion", "Global_and_Local_conv_merge", "Global_only_cyc_nofusion", "Foreground_and_Background",
+                                  "model19", "Global_and_Local_CPS"])
 def test_oracle_variants_match_reference_fixture(golden_dir, name):
     """the single-branch ablations (ours.py:1999-2249), oracle restatement vs the reference's classes."""
     g = np.load(os.path.join(golden_dir, f"variant_{name}.npz"))
