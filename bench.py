@@ -328,6 +328,10 @@ def main():
         prof, iso_steps = [], min(2, args.steps)
         ops.PROFILER = prof
         for _ in range(iso_steps):
+            # keep the launch queue AHEAD of the GPU for the whole step: an event pair around a 40 us kernel measures launch-to-launch
+            # time when the GPU is waiting for the (Python) host -- round 2's per-shape table showed the layer-1 contractions at
+            # 30-60 TF that way; rocprofv3 and isolated runs put them at ~100 TF (HBM-bound).  ~150 ms of spinning first.
+            torch.cuda._sleep(int(3.0e8))
             step()
         fence()
         ops.PROFILER = None

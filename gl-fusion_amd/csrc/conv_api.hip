@@ -135,6 +135,15 @@ extern "C" int glf_conv2d_plan(const glf_conv_params* p, int pass, glf_conv_plan
             plan->M = p->cout; plan->N = p->cin; plan->K = (int)rows_o;
             plan->rect = rect ? 1 : 0;
             plan->split = tn_split(eff, p->cout, p->cin, kept, prec);
+            if (rect) {
+                // slices are cut from the full reduction length (glf_gemm_params.split): a tap uses rows_tap / chunk of them, the
+                // kept taps together ~ kept * frac * split -- scale up so that the launch still fills the chip
+                long long s2 = (long long)((double)plan->split / (frac > 0.02 ? frac : 0.02) + 0.999);
+                const long long cap = rows_o / 512 > 1 ? rows_o / 512 : 1;
+                if (s2 > cap) s2 = cap;
+                if (s2 > 65535) s2 = 65535;
+                plan->split = (int)(s2 < 1 ? 1 : s2);
+            }
             plan->workspace_bytes = plan->split > 1 ? (int64_t)plan->split * kept * p->cout * p->cin * (int64_t)sizeof(float) : 0;
             plan->zero_fill = mask != ((taps == 32) ? 0xffffffffu : ((1u << taps) - 1u));     // taps outside the mask stay zero
         }

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_bf16s_kernel(const GemmAr
         r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
         pKe = g_nimg * r_h * r_w;
     }
-    int chunk = (pKe + p_split - 1) / p_split;
+    int chunk = (pK + p_split - 1) / p_split;       // slices are cut from the FULL reduction length: a tap with a short rectangle uses fewer of them
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
     const int r1 = min(pKe, r0 + chunk);

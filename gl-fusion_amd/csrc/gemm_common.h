@@ -39,6 +39,9 @@ int launch_tn_bf16s(const GemmArgs& a, dim3 grid, bool gather, hipStream_t s);
 int init_gemm_f16s_attrs();                    // gemm_f16s.hip
 int launch_rows_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);   // nprod: 3 = f16x3, 1 = f16
 int launch_tn_f16s(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);
+int init_gemm_f16s4_attrs();                   // gemm_f16s4.hip: the 4-wave 128 x 128 NT configuration (two workgroups per CU)
+bool use_f16s4(const GemmArgs& a);
+int launch_rows_f16s4(const GemmArgs& a, dim3 grid, bool gather, int nprod, hipStream_t s);
 int launch_amax(const float* x, long long rows, int cols, long long ld, int vec, float* out, hipStream_t s);
 int launch_split_packed(const float* x, long long rows, int cols, long long ld, const float* amax, float* out, long long ldo, hipStream_t s);   // gemm_f16s.hip
 float* amax_scratch(int n, hipStream_t s);     // n consecutive device floats from the ring of stream s (glf_api.hip)

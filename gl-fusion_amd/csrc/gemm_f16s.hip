@@ -62,6 +62,7 @@ namespace {
 // ----------------------------------------------------------------------------------------------------------
 constexpr int BM8 = 256;
 constexpr int NT8 = 512;
+constexpr int WAVE_ROWS = 4;            // wave rows of the 8-wave NT workgroup (4 x 2 waves of 64 x 64)
 #ifndef GLF_MFMA16_PRESPLIT_DEFAULT
 #define GLF_MFMA16_PRESPLIT_DEFAULT 0
 #endif
@@ -1001,13 +1002,30 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             }
         }
         if (p_colstats) {
-            // lanes l, l + 16, l + 32, l + 48 hold the four row groups of the same four columns
+            // lanes l, l + 16, l + 32, l + 48 hold the four row groups of the same four columns; the wave rows of the workgroup
+            // are then folded through LDS (each wave's own parking area is free once its stores are issued), so that ONE f64
+            // atomic per column, statistic and WORKGROUP reaches memory.  Per wave it was M / 64 atomics on each of the N
+            // addresses: 3 025 per address on a 193 600-row layer-1 conv output -- ~150 us of serialised atomics behind a 60 us
+            // contraction (profiles/r03_colstats_atomics.txt).
             double* st = args.colstats;
+            double* fold = reinterpret_cast<double*>(tile);              // [64 columns][2]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 cs[j] += __shfl_xor(cs[j], 16, 64); cq[j] += __shfl_xor(cq[j], 16, 64);
                 cs[j] += __shfl_xor(cs[j], 32, 64); cq[j] += __shfl_xor(cq[j], 32, 64);
-                if (lane < 16 && col + j < pN) { atomicAdd(st + col + j, cs[j]); atomicAdd(st + pN + col + j, cq[j]); }
+                if (lane < 16) { fold[2 * (c4 + j)] = cs[j]; fold[2 * (c4 + j) + 1] = cq[j]; }
+            }
+            __syncthreads();
+            if (wm == 0) {                                               // waves 0 / 1: the two column halves of the tile
+                const int cl = lane;                                     // column within the wave's 64
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int w = 0; w < WAVE_ROWS; ++w) {
+                    const double* f = reinterpret_cast<const double*>(reinterpret_cast<const float*>(smem_s) + (2 * w + (wave & 1)) * (64 * 64));
+                    s += f[2 * cl]; q += f[2 * cl + 1];
+                }
+                const int cg = tn * BN + wn + cl;
+                if (cg < pN) { atomicAdd(st + cg, s); atomicAdd(st + pN + cg, q); }
             }
         }
     } else if (!M16) {
@@ -1063,7 +1081,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     if (args.amax_c && p_rect != 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
-        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+        if (lane == 0 && cmax > *reinterpret_cast<volatile float*>(args.amax_c))      // thousands of waves, ONE address: only a wave that raises it
+            atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
     }
 #if defined(GLF_STAMPS) && GLF_STAMPS == 2
     if (args.partial != nullptr && blockIdx.x == gridDim.x / 2) {
@@ -1141,7 +1160,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
         r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
         pKe = g_nimg * r_h * r_w;
     }
-    int chunk = (pKe + p_split - 1) / p_split;
+    int chunk = (pK + p_split - 1) / p_split;       // slices are cut from the FULL reduction length: a tap with a short rectangle uses fewer of them
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
     const int r1 = min(pKe, r0 + chunk);
@@ -1271,7 +1290,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     if (args.amax_c && !atomic && !args.partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
-        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+        if (lane == 0 && cmax > *reinterpret_cast<volatile float*>(args.amax_c))      // thousands of waves, ONE address: only a wave that raises it
+            atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
     }
 }
 
@@ -1341,7 +1361,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
         r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
         pKe = g_nimg * r_h * r_w;
     }
-    int chunk = (pKe + p_split - 1) / p_split;
+    int chunk = (pK + p_split - 1) / p_split;       // slices are cut from the FULL reduction length: a tap with a short rectangle uses fewer of them
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
     const int r1 = min(pKe, r0 + chunk);
@@ -1602,7 +1622,8 @@ __global__ __launch_bounds__(NT8, 2) void gemm_tn_f16s8_kernel(const GemmArgs ar
     if (args.amax_c && !atomic && !args.partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
-        if (lane == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
+        if (lane == 0 && cmax > *reinterpret_cast<volatile float*>(args.amax_c))      // thousands of waves, ONE address: only a wave that raises it
+            atomicMax(reinterpret_cast<unsigned*>(args.amax_c), __float_as_uint(cmax));
     }
 #if defined(GLF_STAMPS) && GLF_STAMPS == 2
     if (args.stamps != nullptr && blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && blockIdx.y == 0) {
@@ -1697,7 +1718,7 @@ int init_gemm_f16s_attrs() {
 #undef SET_TN
 #undef SET_ROWS
 #undef SET_ATTR
-    return GLF_OK;
+    return init_gemm_f16s4_attrs();
 }
 
 // Eligibility: the aligned fast path, and every row that can be redirected to the zero page must fit into it.
@@ -1721,6 +1742,7 @@ extern "C" int glf_debug_stamps(void* host_out) {          // [8 waves][16 itera
 #endif
 
 int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStream_t s) {
+    if (use_f16s4(a0)) return launch_rows_f16s4(a0, grid, gather, nprod, s);      // short reductions: two workgroups per CU
     GemmArgs a = a0;
     a.zeros = zero_page();
     long long tiles_m = (a.M + BM8 - 1) / BM8;

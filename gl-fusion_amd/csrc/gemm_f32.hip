@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const GemmArgs arg
         r_y0 = y0; r_x0 = x0; r_h = y1 - y0; r_w = x1 - x0;
         pKe = g_nimg * r_h * r_w;
     }
-    int chunk = (pKe + p_split - 1) / p_split;
+    int chunk = (pK + p_split - 1) / p_split;       // slices are cut from the FULL reduction length: a tap with a short rectangle uses fewer of them
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int r0 = sl * chunk;
     const int r1 = min(pKe, r0 + chunk);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
         tap_rect(1, tap, g.kw, g.pad, g.dil, g.hs, g.ws, g.hd, g.wd, y0, y1, x0, x1);
         pKe = g.n_img * (y1 - y0) * (x1 - x0);
     }
-    int chunk = (pKe + split - 1) / split;
+    int chunk = (K + split - 1) / split;                // as in the kernels: from the full reduction length
     chunk = ((chunk + BK - 1) / BK) * BK;
     const int nvalid = chunk > 0 ? min(split, (pKe + chunk - 1) / chunk) : 0;       // slices that ran (the others returned early)
     const long long mn = (long long)M * N;

@@ -49,12 +49,16 @@ __device__ __forceinline__ float bn_val(float x, float mu, float is, float ga, f
 struct OpBnBwd {          // (dy', dy' * xhat), dy' = dy * (y > 0) when relu; y == NULL: the mask is recomputed from x
     const float* dy; int lddy; const float* x; int ldx; const float* y; int ldy;
     const float* mean; const float* invstd; const float* gamma; const float* beta; int relu;
+    const unsigned char* mask; int c4;          // relu with a residual: the forward's sign bits, one byte per float4 (instead of y)
     __device__ void operator()(int r, int c, float4& a, float4& b) const {
         a = *reinterpret_cast<const float4*>(dy + (long long)r * lddy + c);
         const float4 xx = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        if (relu) {
+        if (relu && mask) {
+            const unsigned m = mask[(long long)r * c4 + (c >> 2)];
+            a.x = (m & 1u) ? a.x : 0.f; a.y = (m & 2u) ? a.y : 0.f; a.z = (m & 4u) ? a.z : 0.f; a.w = (m & 8u) ? a.w : 0.f;
+        } else if (relu) {
             float4 yy;
             if (y) {
                 yy = *reinterpret_cast<const float4*>(y + (long long)r * ldy + c);
@@ -337,7 +341,7 @@ __device__ __forceinline__ void block_amax(float m, float* __restrict__ amax_out
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res, int ldr,
                                                        float* __restrict__ y, int ldy, Coef k, long long total4, int c4, int relu,
-                                                       float* __restrict__ amax_out) {
+                                                       float* __restrict__ amax_out, unsigned char* __restrict__ mask) {
     float am = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + c);
             o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
+        if (mask) mask[i] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(y + r * ldy + c) = o;
         am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
@@ -370,7 +375,8 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restr
                                                             float* __restrict__ y, int ldy, const double* __restrict__ sums, int rows, int c,
                                                             float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out, float* rmean, float* rvar,
-                                                            long long* nbt, long long total4, int c4, int relu, float* __restrict__ amax_out) {
+                                                            long long* nbt, long long total4, int c4, int relu, float* __restrict__ amax_out,
+                                                            unsigned char* __restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) float s_coef[];       // [2][c]: mean, invstd
     float* s_mean = s_coef;
     float* s_is = s_coef + c;
@@ -406,6 +412,7 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restr
             const float4 rr = *reinterpret_cast<const float4*>(res + r * ldr + cc);
             o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
+        if (mask) mask[i] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
         am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
                                                            long long total4, int c4, int relu, int training, float inv_n,
-                                                           float* __restrict__ amax_out, int packed) {
+                                                           float* __restrict__ amax_out, int packed, const unsigned char* __restrict__ mask) {
     // packed != 0: dx is written as the packed pre-split fp16 image (glf_split_f16_packed's format) scaled by *amax_out, which
     // then holds an upper bound of max |dx| computed by bnbwd_finalize (not a by-product of this kernel)
     float am = 0.f, sc = 1.f, sc_inv = 1.f;
@@ -431,11 +438,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
         const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
         float4 xx = make_float4(0.f, 0.f, 0.f, 0.f), mu = xx;
-        if (training || (relu && !y)) {
+        if (training || (relu && !y && !mask)) {
             xx = *reinterpret_cast<const float4*>(x + r * ldx + c);
             mu = *reinterpret_cast<const float4*>(k.mean + c);
         }
-        if (relu) {
+        if (relu && mask) {
+            const unsigned m = mask[i];
+            g.x = (m & 1u) ? g.x : 0.f; g.y = (m & 2u) ? g.y : 0.f; g.z = (m & 4u) ? g.z : 0.f; g.w = (m & 8u) ? g.w : 0.f;
+        } else if (relu) {
             float4 yy;
             if (y) {
                 yy = *reinterpret_cast<const float4*>(y + r * ldy + c);
@@ -644,7 +654,7 @@ extern "C" int glf_bn_eval_coeffs(const float* rm, const float* rv, float eps, f
 
 extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                            int rows, int c, int relu, float* amax_out, glf_stream_t s) {
+                            int rows, int c, int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply: null argument");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply: rows must be > 0");
@@ -652,14 +662,14 @@ extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int 
     if (residual) { REQ_AL(residual, "residual"); REQ_LD(ldr, "ldr"); }
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), x, ldx, residual, ldr, y, ldy,
-                       Coef{mean, invstd, gamma, beta}, total4, c / 4, relu, amax_out);
+                       Coef{mean, invstd, gamma, beta}, total4, c / 4, relu, amax_out, relu_mask);
     return glf::check_launch("bn_apply");
 }
 
 extern "C" int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
                                       int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
                                       float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                      int relu, float* amax_out, glf_stream_t s) {
+                                      int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y && sums && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply_from_sums: null argument");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply_from_sums: rows must be > 0");
@@ -670,24 +680,26 @@ extern "C" int glf_bn_apply_from_sums(const float* x, int ldx, const float* resi
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_apply_sums_kernel, dim3(stream_grid(total4, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s), x, ldx, residual, ldr, y, ldy, sums, rows, c,
                        eps, momentum, gamma, beta, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked),
-                       total4, c / 4, relu, amax_out);
+                       total4, c / 4, relu, amax_out, relu_mask);
     return glf::check_launch("bn_apply_from_sums");
 }
 
 extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-                          int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx, glf_stream_t s) {
+                          int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
+                          const uint8_t* relu_mask, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
+    if (relu_mask) y = nullptr;
     GLF_REQUIRE(!packed_dx || amax_out, GLF_ERR_NULL, "bn_bwd: packed_dx needs amax_out (a zeroed device float that receives the bound the image is scaled with)");
-    GLF_REQUIRE(!relu || y || beta, GLF_ERR_NULL, "bn_bwd: relu != 0 needs y (the forward output) or beta (to recompute its sign from x)");
+    GLF_REQUIRE(!relu || y || beta || relu_mask, GLF_ERR_NULL, "bn_bwd: relu != 0 needs relu_mask, y (the forward output) or beta (to recompute its sign from x)");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_bwd: rows must be > 0");
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
     if (relu && y) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
     const int slices = n_slices_c(rows, c);
-    const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu};
+    const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu, relu_mask, c / 4};
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
     float* s_dy = dbeta ? dbeta : sums;
@@ -707,7 +719,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
                        Coef{mean, invstd, gamma, beta}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
-                       1.0f / (float)rows, amax_out, packed_dx);
+                       1.0f / (float)rows, amax_out, packed_dx, relu_mask);
     return glf::check_launch("bn_bwd_apply");
 }
 

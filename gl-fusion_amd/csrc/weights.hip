@@ -27,6 +27,12 @@ __device__ __forceinline__ void job_copy(const glf_weight_job& j, long long wg) 
     }
 }
 
+__device__ __forceinline__ void job_zero(const glf_weight_job& j, long long wg) {
+    const long long n = j.d0, base = wg * ELEMS_PER_WG;
+    const long long hi = base + ELEMS_PER_WG < n ? base + ELEMS_PER_WG : n;
+    for (long long i = base + threadIdx.x; i < hi; i += WB) j.dst[i] = 0.f;
+}
+
 __device__ __forceinline__ void job_amax(const glf_weight_job& j, long long wg) {
     const long long n = j.d0, base = wg * ELEMS_PER_WG;
     const long long hi = base + ELEMS_PER_WG < n ? base + ELEMS_PER_WG : n;
@@ -114,13 +120,14 @@ __global__ __launch_bounds__(WB) void weights_refresh_kernel(const glf_weight_jo
         case GLF_WJ_TAP_MAJOR_T: job_tap_major_t(j, wg); break;
         case GLF_WJ_TRANSPOSE: job_transpose(j, wg); break;
         case GLF_WJ_PACK: job_pack(j, wg); break;
+        case GLF_WJ_ZERO: job_zero(j, wg); break;
         default: break;
     }
 }
 
 long long job_workgroups(const glf_weight_job& j) {
     switch (j.kind) {
-        case GLF_WJ_COPY: case GLF_WJ_AMAX: case GLF_WJ_PACK: return ((long long)j.d0 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
+        case GLF_WJ_COPY: case GLF_WJ_AMAX: case GLF_WJ_PACK: case GLF_WJ_ZERO: return ((long long)j.d0 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
         case GLF_WJ_TAP_MAJOR: case GLF_WJ_TAP_MAJOR_T: return ((long long)j.d0 * j.d1 * j.d2 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
         case GLF_WJ_TRANSPOSE: return (long long)((j.d0 + 31) / 32) * ((j.d1 + 31) / 32);
         default: return -1;
@@ -137,8 +144,8 @@ extern "C" int glf_weights_plan(glf_weight_job* jobs_host, int n_jobs, int* pass
         glf_weight_job& j = jobs_host[i];
         GLF_REQUIRE(j.pass >= 0 && j.pass < GLF_WJ_PASSES && j.pass >= prev, GLF_ERR_BAD_SHAPE,
                     "weights_plan: job %d: pass %d out of range or jobs not sorted by pass", i, j.pass);
-        GLF_REQUIRE(j.src && (j.dst || j.kind == GLF_WJ_AMAX), GLF_ERR_NULL, "weights_plan: job %d: null tensor", i);
-        GLF_REQUIRE(j.d0 > 0 && (j.kind == GLF_WJ_COPY || j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK || j.d1 > 0), GLF_ERR_BAD_SHAPE,
+        GLF_REQUIRE((j.src || j.kind == GLF_WJ_ZERO) && (j.dst || j.kind == GLF_WJ_AMAX), GLF_ERR_NULL, "weights_plan: job %d: null tensor", i);
+        GLF_REQUIRE(j.d0 > 0 && (j.kind == GLF_WJ_COPY || j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK || j.kind == GLF_WJ_ZERO || j.d1 > 0), GLF_ERR_BAD_SHAPE,
                     "weights_plan: job %d: bad extents", i);
         if (j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK) GLF_REQUIRE(j.amax, GLF_ERR_NULL, "weights_plan: job %d needs an amax scalar", i);
         if (j.kind == GLF_WJ_PACK)

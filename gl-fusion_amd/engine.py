@@ -75,10 +75,12 @@ class StepGraph:
         prev_distinct, ops.SECTIONS_DISTINCT = ops.SECTIONS_DISTINCT, True
         self._prev_distinct = prev_distinct
 
+        self.wtable = None                         # frozen job table of THIS model's weight images (made after the warm-up)
+
         def body():
             ops.advance_step(dev)
             if refresh_weights:
-                ops.refresh_weights()
+                ops.refresh_weights(self.wtable)   # warm-up: the registry-wide refresh; captured: this model's images only
             for p in self.params:
                 p.grad = None
             return step_fn()
@@ -95,6 +97,10 @@ class StepGraph:
             for p in self.params:
                 p.grad = None
             ops.reset_capture_pools()
+            if refresh_weights:
+                # the captured refresh replays against a table of its own: it names only this model's images and keeps their
+                # buffers alive, so nothing another model (or the garbage collector) does to the registry can invalidate it
+                self.wtable = ops.freeze_weight_table(self.params)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.out = body()
@@ -119,6 +125,7 @@ class StepGraph:
         self.graph = None
         self.out = None
         self.grads = {}
+        self.wtable = None
 
 
 class Trainer:

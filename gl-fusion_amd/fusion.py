@@ -67,6 +67,7 @@ def _qkv_weights(params):
         bcat = torch.empty(3 * ci, dtype=torch.float32, device=th_w.device)
         refs = [weakref.ref(t) for t in params]
         Wcat._glf_version_fn = lambda refs=refs: tuple((r()._version, r().data_ptr()) if r() is not None else None for r in refs)
+        Wcat._glf_sources = refs
         hit = _qkv_cache[key] = (weakref.ref(th_w, lambda _r, k=key: _qkv_cache.pop(k, None)), Wcat, bcat)
     _, Wcat, bcat = hit
     for i, (w, b) in enumerate(((th_w, th_b), (ph_w, ph_b), (g_w, g_b))):
@@ -200,7 +201,7 @@ class TpaviFn(Function):
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), 0, _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), 0, None, _stream()), "bn_bwd")
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)

@@ -19,6 +19,8 @@ from .segmentation import deeplabv3_resnet50_iekd
 
 # the two fusion blocks on side streams of their own (GLF_FUSION_STREAMS=0: one after the other on the current stream)
 _FUSION_STREAMS = os.environ.get("GLF_FUSION_STREAMS", "1") != "0"
+# classifier and centerness head of a view on streams of their own (inside the view's section)
+_HEAD_STREAMS = os.environ.get("GLF_HEAD_STREAMS", "0") != "0"
 
 class TPAVIModule(nn.Module):
     """ours.py:770-917.  Built modes: 'dot' (shipped) and 'embedded' (softmax); dimension=3,
@@ -145,8 +147,12 @@ class Global_and_Local(_PerViewNetworks):
         def view_section(v):
             f = self._encode_view(v, x[v])
             fa, fb, fc, fg, *raw = ops.fan_out(f, 5 if self._third_output_is_f4 else 4)   # classifier / centerness / gate / global fusion
-            cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
-            ctr = self.centerness[v].forward_nhwc(fb)
+            if _HEAD_STREAMS:            # the two heads of a view are independent chains of ~25 kernels each
+                (cls, again), ctr = ops.parallel_sections([lambda: self.classifier[v].forward_nhwc_shared(fa),
+                                                           lambda: self.centerness[v].forward_nhwc(fb)])
+            else:
+                cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
+                ctr = self.centerness[v].forward_nhwc(fb)
             gated = ops.local_gate(cls, ctr, fc, self.center_aware_weight)
             if self._global_gets_background:                            # Foreground_and_Background (ours.py:2966)
                 g1, g2 = ops.fan_out(gated, 2)

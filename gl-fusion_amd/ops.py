@@ -19,7 +19,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import GemmParams, WeightJob, WJ_AMAX, WJ_COPY, WJ_PACK, WJ_PASSES, WJ_PASS_OF, WJ_TAP_MAJOR, WJ_TAP_MAJOR_T, WJ_TRANSPOSE, check, lib
+from ._lib import GemmParams, WeightJob, WJ_AMAX, WJ_COPY, WJ_PACK, WJ_PASSES, WJ_PASS_OF, WJ_TAP_MAJOR, WJ_TAP_MAJOR_T, WJ_TRANSPOSE, WJ_ZERO, check, lib
 
 
 # ----------------------------------------------------------------------------------------
@@ -246,24 +246,44 @@ class _WeightRegistry:
             if im.kind == 1 and self.arena is not None and im.amax is not None:        # 1 == WJ_AMAX (a literal: see drop at shutdown)
                 self.free.append(int((im.amax.data_ptr() - self.arena.data_ptr()) // 4))
 
-    def build(self) -> None:
-        ims = sorted(self.images.values(), key=lambda im: WJ_PASS_OF[im.kind])
-        n = len(ims)
+    def build(self, only=None):
+        """Plan the job table of the registered images and copy it to the device.  only = None: all of them, installed as the
+        registry's own table (rebuilt whenever an image is added or dropped; its refresh zero-fills the whole amax arena).
+        only = a set of owner ids: a FROZEN table of those owners' images, returned to the caller together with strong
+        references to every buffer it names -- what a captured hipGraph replays against (engine.StepGraph), valid however
+        the registry changes afterwards; it zeroes exactly its own amax slots (GLF_WJ_ZERO jobs)."""
+        ims = [im for im in self.images.values() if only is None or _image_belongs(im, only)]
+        jobs = []                                  # (kind, src ptr, dst ptr, amax ptr, dims)
+        for im in ims:
+            jobs.append((im.kind, im.src.data_ptr(), im.dst.data_ptr() if im.dst is not None else 0,
+                         im.amax.data_ptr() if im.amax is not None else 0, im.dims))
+            if only is not None and im.kind == WJ_AMAX:
+                jobs.append((WJ_ZERO, 0, im.amax.data_ptr(), 0, (1, 0, 0)))
+        jobs.sort(key=lambda j: WJ_PASS_OF[j[0]])
+        n = len(jobs)
         arr = (WeightJob * max(n, 1))()
-        for j, im in zip(arr, ims):
-            j.src, j.dst = im.src.data_ptr(), (im.dst.data_ptr() if im.dst is not None else 0)
-            j.amax = im.amax.data_ptr() if im.amax is not None else 0
-            j.kind, j.pass_ = im.kind, WJ_PASS_OF[im.kind]
-            j.d0, j.d1, j.d2 = im.dims
+        for j, (kind, src, dst, am, dims) in zip(arr, jobs):
+            j.src, j.dst, j.amax, j.kind, j.pass_ = src, dst, am, kind, WJ_PASS_OF[kind]
+            j.d0, j.d1, j.d2 = dims
         pf, pc, pw = (C.c_int * WJ_PASSES)(), (C.c_int * WJ_PASSES)(), (C.c_int64 * WJ_PASSES)()
         check(lib.glf_weights_plan(C.cast(arr, C.c_void_p), n, C.cast(pf, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(pw, C.c_void_p)), "weights_plan")
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self.table = (host.to(self.dev), pf, pc, pw, n)
+        table = (host.to(self.dev), pf, pc, pw, n)
+        if only is not None:
+            return table + ([(im.src, im.dst, im.amax) for im in ims], self.arena)
+        self.table = table
         self.dirty = False
+        return None
 
-    def refresh(self) -> None:
+    def refresh(self, frozen=None) -> None:
+        if frozen is not None:                     # a frozen table: no bookkeeping (its owner re-stamps nothing; eager callers
+            tab, pf, pc, pw, n = frozen[:5]        # of the same parameters find their caches stale and rebuild in place)
+            if n:
+                check(lib.glf_weights_refresh(_p(tab), C.cast(pf, C.c_void_p), C.cast(pc, C.c_void_p), C.cast(pw, C.c_void_p),
+                                              None, 0, _stream()), "weights_refresh")
+            return
         if torch.cuda.is_current_stream_capturing() and self.dirty:
-            raise RuntimeError("glfusion_amd: the weight-image table changed inside a graph capture (run a warm-up step first)")
+            raise RuntimeError("glfusion_amd: the weight-image table changed inside a graph capture (freeze a table first)")
         if self.dirty:
             self.build()
         tab, pf, pc, pw, n = self.table
@@ -276,6 +296,18 @@ class _WeightRegistry:
                 im.version = _wversion(o, im)
                 if im.kind == WJ_AMAX:
                     o._glf_amax = (o._version, o.data_ptr(), im.amax)
+
+
+def _image_belongs(im, owner_ids) -> bool:
+    """True when the image derives from one of the given parameters: directly, or through a stacked operand assembled from
+    them (fusion._qkv_weights marks it with `_glf_sources`)."""
+    o = im.owner()
+    if o is None:
+        return False
+    if id(o) in owner_ids:
+        return True
+    srcs = getattr(o, "_glf_sources", None)
+    return srcs is not None and any(r() is not None and id(r()) in owner_ids for r in srcs)
 
 
 _wreg = {}
@@ -320,13 +352,30 @@ def _wimage(owner: torch.Tensor, tag: str, kind: int, src: torch.Tensor, dims, m
     return im, True
 
 
-def refresh_weights() -> None:
+def refresh_weights(frozen=None) -> None:
     """Recompute every registered weight-derived image from the current parameter values (four launches per device on the
     current stream) and mark the caches current.  Call after an optimizer step wrote the parameters (glfusion_amd.optim.Adam
-    does); anything not registered yet is still rebuilt lazily by its cache."""
+    does); anything not registered yet is still rebuilt lazily by its cache.  frozen: a table from freeze_weight_table() --
+    only that table's images are recomputed (no cache bookkeeping): the form a captured step replays."""
+    if frozen is not None:
+        for dev, tab in frozen.items():
+            _registry(dev).refresh(tab)
+        return
     for reg in list(_wreg.values()):
         if reg.images:
             reg.refresh()
+
+
+def freeze_weight_table(params) -> dict:
+    """{device: frozen job table} of every image currently registered for the given parameters (run a step first so that
+    they exist).  The tables hold their buffers alive; pass the dict to refresh_weights(frozen=...)."""
+    ids = {id(p) for p in params}
+    out = {}
+    for dev, reg in _wreg.items():
+        tab = reg.build(only=ids)
+        if tab[4]:
+            out[dev] = tab
+    return out
 
 
 def _is_weight(t: torch.Tensor) -> bool:
@@ -459,6 +508,19 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
                 best, best_score = s, score
         want = best
     return int(max(1, min(want, cap, hi)))
+
+
+def wgrad_split(rows_o: int, frac: float, cout: int, cin: int, ntap: int, rect: bool) -> int:
+    """Reduction slices of a convolution's weight gradient (mirror of conv_api.hip's plan).  A slice is ceil(rows / split) rows
+    of EVERY tap's reduction; in rect mode (ASPP: most taps reach only a small rectangle of the map) a tap uses as many slices
+    as its rectangle is long, so the count is scaled up by the in-range fraction to keep the launch at its target size -- and
+    all workgroups reduce the same number of rows (before: every tap was cut into `split` pieces of its own rectangle, the
+    centre tap's workgroups ran 3 x (rate 12) to 50 x (rate 24) longer than the corner taps')."""
+    split = _tn_split(max(512, int(rows_o * frac)) if rect else rows_o, cout, cin, ntap)
+    if rect:
+        s2 = int(split / max(frac, 0.02) + 0.999)
+        split = max(1, min(s2, max(1, rows_o // 512), 65535))
+    return split
 
 
 _ones_cache = {}
@@ -843,7 +905,7 @@ class Conv2dFn(Function):
                 rect = (not plain and taps > 1 and stride == 1 and ntap > 1
                         and rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) < _rect_thr("wgrad"))
                 frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
-                split = _tn_split(max(512, int(rows_o * frac)), cout, cin, ntap)
+                split = wgrad_split(rows_o, frac, cout, cin, ntap, rect)
                 full = mask == (1 << taps) - 1
                 dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
                 ok = tn_presplit_ok(cout, cin, cout, cin)
@@ -1117,6 +1179,7 @@ def _rows_view(t: torch.Tensor):
 # ----------------------------------------------------------------------------------------
 _last_bn = [None]          # (mean, invstd, rows) of the most recent BatchNormActFn.forward (read by BN_TAP)
 FUSE_BN_FINALIZE = os.environ.get("GLF_FUSE_BN_FINALIZE", "1") != "0"     # statistics finished inside the apply kernel
+RELU_MASK_BYTES = os.environ.get("GLF_RELU_MASK_BYTES", "1") != "0"       # BN(+residual)+ReLU keeps sign bytes, not y, for backward
 
 
 class BatchNormActFn(Function):
@@ -1147,16 +1210,20 @@ class BatchNormActFn(Function):
             residual = _contig(_chk(residual, "bn residual"))
         y, ldy, shared = _take_out(x.shape, dev)
         am = shared if shared is not None else amax_slot(dev)
+        # relu + residual: the backward needs the sign of the forward output -- kept as one byte per four channels instead of y
+        need_mask = relu and residual is not None and torch.is_grad_enabled() and RELU_MASK_BYTES
+        mask = torch.empty(rows * (c // 4), dtype=torch.uint8, device=dev) if need_mask else None
         if fused_stats:
             check(lib.glf_bn_apply_from_sums(_p(x), c, _p(residual), c, _p(y), ldy, _p(sums), rows, c, eps, momentum, _p(gamma), _p(beta),
                                              _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), int(relu), _p(am),
-                                             _stream()), "bn_apply_from_sums")
+                                             _p(mask), _stream()), "bn_apply_from_sums")
         else:
             check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
-                                   int(relu), _p(am), _stream()), "bn_apply")
+                                   int(relu), _p(am), _p(mask), _stream()), "bn_apply")
         set_amax(y, am)
         # without a residual the ReLU mask is recomputed from x in backward (sign of the same expression): y is not kept
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, gamma, beta if relu else None)
+        ctx.save_for_backward(x, mask if need_mask else (y if (relu and residual is not None) else None), mean, invstd, gamma, beta if relu else None)
+        ctx.has_mask = need_mask
         ctx.cfg = (rows, c, relu, training, residual is not None, ldy)
         ctx.packed_grad = bool(packed_grad) and _PREC[0] >= 2
         ctx.join = getattr(residual, "_glf_join", None) if residual is not None else None
@@ -1179,9 +1246,10 @@ class BatchNormActFn(Function):
         # packed pre-split image they want (scaled by a bound of its maximum the reduction pass provides), instead of fp32
         # followed by a split pass
         packed = ctx.packed_grad and _PREC[0] >= 2 and am is not None and PACKED_GRADS
-        check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
-                             _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am), int(packed),
-                             _stream()), "bn_bwd")
+        mask = y if ctx.has_mask else None
+        check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, None if ctx.has_mask else _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                             _p(dx), c, _p(dres), c, _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am),
+                             int(packed), _p(mask), _stream()), "bn_bwd")
         set_amax(dx, am)
         if packed:
             dx._glf_packed_only = True
@@ -1458,7 +1526,7 @@ def join_gradients(conv_input: torch.Tensor, shortcut: torch.Tensor) -> None:
 # with another chain's workgroups.  Backward nodes run on the stream their forward ran on (autograd does that), so
 # the overlap carries over.  GLF_STREAMS=0 serialises everything on the current stream.
 STREAMS = os.environ.get("GLF_STREAMS", "1") != "0"
-N_SIDE_STREAMS = 12
+N_SIDE_STREAMS = int(os.environ.get("GLF_SIDE_STREAMS", "24"))
 if STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # parameters' AccumulateGrad nodes live on the stream that first touched them (the default one when a gradient
     # hook keeps them alive); gradients produced on a side stream are synchronised into it, which is intended

@@ -96,7 +96,11 @@ typedef struct {
     float alpha;                /* scale applied to the accumulator                              */
     int32_t accumulate;         /* 1: C += result (fwd/dgrad: read-modify-write; wgrad: atomics) */
     int32_t split;              /* wgrad/TN only: number of reduction slices (>=1); >1 requires  */
-                                /* C zero-filled (or holding the value to accumulate onto)       */
+                                /* C zero-filled (or holding the value to accumulate onto).  A   */
+                                /* slice is ceil(K / split) rows (rounded up to 32) of EVERY      */
+                                /* tap's reduction: in rect mode a tap whose rectangle is short   */
+                                /* uses fewer slices, so all workgroups get reductions of equal   */
+                                /* length whatever the rectangles' sizes.                        */
     int32_t rect;               /* 1: tap-parallel rectangle mode (stride-1 convs whose taps fall */
                                 /* mostly into the padding, i.e. ASPP): each tap runs as its own  */
                                 /* GEMM over exactly its in-range rectangle of pixels; nt/nn sum  */
@@ -257,6 +261,8 @@ enum {
     GLF_WJ_TRANSPOSE = 4,   /* src [d0=rows][d1=cols] -> dst [cols][rows]                       (pass 2) */
     GLF_WJ_PACK = 5,        /* dst = packed pre-split image of src (d0 elements, % 4 == 0, both 16-byte aligned)
                                scaled by *amax, as glf_split_f16_packed                          (pass 3) */
+    GLF_WJ_ZERO = 6,        /* dst[i] = 0, d0 elements (src unused): the amax slots of a table that covers only SOME of an
+                               arena's parameters -- such a caller passes amax_arena = NULL to glf_weights_refresh      (pass 0) */
     GLF_WJ_PASSES = 4
 };
 typedef struct {
@@ -316,9 +322,12 @@ int glf_bn_replay_running(const float* mean, const float* invstd, int rows, int 
  * receives max(*amax_out, max|y|) -- the operand maximum the f16x3 contractions need, for free. */
 int glf_bn_eval_coeffs(const float* running_mean, const float* running_var, float eps,
                        float* mean, float* invstd, int c, glf_stream_t s);
+/* relu_mask (may be NULL): receives the sign of the pre-ReLU value, one byte per four consecutive channels (bit j = element
+ * 4 i + j is positive; [rows][c / 4] dense) -- what glf_bn_bwd needs of the forward output when a residual was added: the
+ * backward passes then read 1 byte where they read 16 (y is the largest tensor class of the path: the block outputs). */
 int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy,
                  const float* mean, const float* invstd, const float* gamma, const float* beta,
-                 int rows, int c, int relu, float* amax_out, glf_stream_t s);
+                 int rows, int c, int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s);
 /* glf_bn_stats_from_sums + glf_bn_apply in ONE launch (train mode, statistics from a contraction's colstats): every
  * workgroup finishes mean / invstd for all channels in LDS, workgroup 0 writes them to mean / invstd (for the backward pass)
  * and updates running_mean / running_var / num_batches_tracked (all three may be NULL).  Bit-identical to the two calls.
@@ -326,7 +335,7 @@ int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float*
 int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
                            int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
                            float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                           int relu, float* amax_out, glf_stream_t s);
+                           int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s);
 /* Backward.  y is the forward output (ReLU mask = y > 0); it may be NULL when relu == 0, and also when
  * relu != 0 and there was NO residual: the mask is then recomputed from x with beta (one tensor read less
  * in both passes; with a residual the sign of y depends on it, so y is required).
@@ -342,7 +351,8 @@ int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int l
 int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                const float* mean, const float* invstd, const float* gamma, const float* beta /* may be NULL with y */,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
-               int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx, glf_stream_t s);
+               int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
+               const uint8_t* relu_mask /* glf_bn_apply's sign bytes: replaces y */, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise pieces of the path.

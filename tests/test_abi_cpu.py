@@ -136,7 +136,7 @@ def test_conv_plan_matches_host_policy():
                 rect = (not plain and taps > 1 and stride == 1 and ntap > 1
                         and ops.rect_fraction(1, ho, wo, h, w, k, k, pad, dil, mask) < ops._rect_thr("wgrad"))
                 frac = ops.rect_fraction(1, ho, wo, h, w, k, k, pad, dil, mask) if rect else 1.0
-                split = ops._tn_split(max(512, int(n * ho * wo * frac)), cout, cin, ntap)
+                split = ops.wgrad_split(n * ho * wo, frac, cout, cin, ntap, rect)
                 assert (pl.tap_mask, pl.rect, pl.split) == (mask, int(rect), split), (prec, "wgrad", n, h, cin, cout, k, dil, pl.split, split)
         finally:
             ops.set_precision("f32")

@@ -285,7 +285,7 @@ def test_step_graph_replay_matches_eager_step(prec):
             # replay saw the updated weights (the loss moved by far more than the tolerance) -- step 0 is the tight comparison
             assert abs(loss - want[k][0]) <= (1e-6 if k == 0 else 1e-3) * abs(want[k][0]), (k, loss, want[k][0])
             if k == 1:
-                assert abs(want[1][0] - want[0][0]) > 1e-2 * abs(want[0][0]), "the test's update is too small to tell stale weights"
+                assert abs(want[1][0] - want[0][0]) > 5e-3 * abs(want[0][0]), "the test's update is too small to tell stale weights"
                 break
             # floor: a conv bias in front of a train-mode BatchNorm has a structurally zero gradient -- what two runs hold
             # there is rounding noise of the float-atomic ASPP rectangles, different from run to run in eager mode too

@@ -548,7 +548,7 @@ def test_bn_backward_writes_packed_gradient(relu, res, training, shape):
             ws = torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=DEV)
             p = lambda t: None if t is None else t.data_ptr()
             check(lib.glf_bn_bwd(p(dy), c, p(x), c, p(y) if (relu and res) else None, c, p(mean), p(invstd), p(gamma), p(beta), p(dx), c,
-                                 p(dres), c, p(dg), p(db), rows, c, int(relu), int(training), p(ws), p(am), packed, None), "bn_bwd")
+                                 p(dres), c, p(dg), p(db), rows, c, int(relu), int(training), p(ws), p(am), packed, None, None), "bn_bwd")
             torch.cuda.synchronize()
             outs.append((dx, dres, dg, db, float(am)))
         (dx0, dres0, dg0, db0, am0), (pk, dres1, dg1, db1, bound) = outs
