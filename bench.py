@@ -132,7 +132,7 @@ def cpu_baseline(frames_per_view: int = 8, steps: int = 3):
                       f"{steps} timed step(s) after 1 warm-up, {dt:.2f} s/step, scaled per frame to a 16-frame clip"}
 
 
-def self_launch(n: int) -> int:
+def self_launch(n: int, script: str = None, argv=None) -> int:
     """`python bench.py --gpus N` from a plain shell: start N fresh rank processes (one per GPU; RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, the same contract torch.distributed.run uses) BEFORE anything in this
     process touches a GPU, relay rank 0's JSON line, and return non-zero if any rank fails.  No exec of a process that
@@ -146,7 +146,7 @@ def self_launch(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(sys.argv[1:] if argv is None else argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
@@ -296,6 +296,7 @@ def main():
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
         eager_ms = None
+        allreduce_ms = round(reducer.last_allreduce_ms(), 3) if (world > 1 and sg is not None and reducer.last_allreduce_ms() is not None) else None
         if sg is not None:
             sg.release()
             sg = None
@@ -336,7 +337,7 @@ def main():
         fence()
         ops.PROFILER = None
         ops.STREAMS = streams
-        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "eager_ms": eager_ms, "host_first": host_first}
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "eager_ms": eager_ms, "host_first": host_first, "allreduce_ms": allreduce_ms}
 
     def roofline_of(leg):
         precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
@@ -459,6 +460,7 @@ def main():
                        "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU",
                        "ranks_in_collective": ranks_seen,
+                       "allreduce_ms_per_step": main_leg.get("allreduce_ms"),
                        "collective_backend": (os.environ.get("GLF_DIST_BACKEND", "nccl") if world > 1 else None)},
             "numerics": {"f32": "exact fp32 MFMA",
                          "bf16x6": "fp32 operands and results; each product = 6 bf16 MFMAs on an exact 3-way split, fp32 accumulate; "

@@ -22,23 +22,6 @@
 #include "split_f16.h"
 #include <cstdlib>
 
-// default MFMA shape of the NT kernel: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 (GLF_MFMA16 overrides)
-#ifndef GLF_MFMA16_DEFAULT
-#define GLF_MFMA16_DEFAULT false
-#endif
-#ifndef GLF_GROUP_M_DEFAULT
-#define GLF_GROUP_M_DEFAULT 0
-#endif
-#ifndef GLF_PING_DEFAULT
-#define GLF_PING_DEFAULT false
-#endif
-#ifndef GLF_DEEP_DEFAULT
-#define GLF_DEEP_DEFAULT false
-#endif
-#ifndef GLF_SETPRIO_DEFAULT
-#define GLF_SETPRIO_DEFAULT 0
-#endif
-
 namespace {
 
 #define GLF_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
@@ -63,9 +46,6 @@ namespace {
 constexpr int BM8 = 256;
 constexpr int NT8 = 512;
 constexpr int WAVE_ROWS = 4;            // wave rows of the 8-wave NT workgroup (4 x 2 waves of 64 x 64)
-#ifndef GLF_MFMA16_PRESPLIT_DEFAULT
-#define GLF_MFMA16_PRESPLIT_DEFAULT 0
-#endif
 #ifndef GLF_IL_ALL          // 1: the slot-interleaved iteration also when neither operand is pre-split
 #define GLF_IL_ALL 1
 #endif
@@ -87,17 +67,9 @@ constexpr size_t SMEM_ROWS_H8 = 3 * BUF8 + 16;
 // scale of args.amax_a / amax_b.  Same byte size, same strides, same addressing as the fp32 operand -- the staging path keeps its
 // loads, pointers, zero page and gather logic and only drops the conversion (a bit-cast instead of ~18 VALU per float4): the
 // operand is split ONCE (by glf_split_f16_packed, per tensor) instead of in every tile of every launch that reads it.
-// DEEP: TWO raw register sets, so a tile's global loads are issued two iterations before they are converted (one with
-// the default pipeline) -- the kernel waits on its load path (SQ_WAIT_ANY 28 %; 48 KB in flight per CU against ~2.5 us of
-// loaded-fabric latency covers ~19 GB/s per CU, the kernel wants 28) -- paid for with the second fragment set: the k-step-1
-// fragments are read into the same registers in the middle of the iteration, behind two conversion pieces.
-// PING: the iteration is cut into a pure-MFMA segment (24 back-to-back MFMAs on fragments already in registers) and a staging
-// segment (convert + store the next tile, issue the loads of the one after, read the fragments of the tile to multiply next),
-// separated by barriers, and waves 4-7 run half an iteration behind waves 0-3: on every SIMD one wave is in its matrix
-// segment while its partner is in its vector / LDS segment (MI355X_MICROARCH.md, "Two waves per SIMD").  The default body
-// interleaves both kinds of work inside every wave, the two waves of a SIMD run it in lockstep, and the measured iteration
-// time is the SUM of both waves' MFMA and VALU time.
-template <bool GATHER, int NP, bool M16, bool BP, bool DEEP = false, bool PING = false, bool PA = false>
+// (The variants that were measured and dropped -- deeper register prefetch, ping-pong segments, sched_group_barrier interleave,
+// static wave priorities, other tile-group sizes -- are described with their numbers in DESIGN.md section 8; their code is gone.)
+template <bool GATHER, int NP, bool M16, bool BP, bool PA = false>
 __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs args) {
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather, p_accumulate = args.accumulate;
@@ -262,7 +234,6 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 
     const int nkc = pK / BK;
     const int ntiles = __popc(mask) * nkc;
-    if ((args.flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half (no per-phase flips)
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};      // main products
     f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};      // mixed products (x 2^11)
     float4 ra[4], rb[2];
@@ -271,15 +242,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
     const float* pa[4];
     const float* pb[2];
 
-    int tiles_left = ntiles;                  // DEEP pads the tile count to even: the tile after the last real one reads zeros
     auto advance = [&]() __attribute__((always_inline)) {
-        if (DEEP && tiles_left-- <= 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pa[j] = p_zero + 4 * ac;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) pb[j] = p_zero + 4 * ac;
-            return;
-        }
         if (++kc >= nkc) {
             kc = 0;
             tap = __ffs(rem_mask) - 1;
@@ -362,7 +325,7 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         default: if (conv_) GLF_H8_CONV_B(1, buf_) GLF_H8_PIN(BP) if (load_) GLF_H8_LOAD_B(1) GLF_H8_PIN(BP) break;     \
     }
 
-    if (!M16 && !DEEP && !PING && ntiles > 0) {
+    if (!M16 && ntiles > 0) {
         const int sw = (lane >> 2) & 3, hh = lane >> 5;
         const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
         const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
@@ -430,25 +393,6 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
         GLF_H8_FRAGS(f, 0, fo0)
         int cur = 0, nxt = 1, wr = 2;           // LDS buffers of tile it, it+1, it+2
         // CONV_/LOAD_/NEXT_ are compile-time constants: the steady-state body is straight-line code
-// GLF_SGB: ask the machine scheduler for an even interleave -- one MFMA, then ~five VALU instructions of the conversion
-// pieces (an MFMA keeps the SIMD's vector issue for 8 of its 32 cycles: ~24 cycles = 5-6 plain VALU fit behind each) --
-// instead of the bursts it picks by itself (five MFMAs back to back, then 9-12 VALU with the matrix pipe idle).
-#ifndef GLF_SGB
-#define GLF_SGB 0
-#endif
-#if GLF_SGB
-#define GLF_SGB_HALF()                                                                                        \
-            _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                \
-                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                            \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-                    __builtin_amdgcn_sched_group_barrier(0x002, GLF_SGB, 0);                                  \
-                }                                                                                             \
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                            \
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
-            }
-#else
-#define GLF_SGB_HALF()
-#endif
 #if defined(GLF_STAMPS) && GLF_STAMPS == 1
         unsigned long long st_[5] = {0, 0, 0, 0, 0};
         const bool stamp_on = args.partial != nullptr && blockIdx.x == gridDim.x / 2;
@@ -476,7 +420,6 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             GLF_H8_PIECE(1, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
             GLF_H8_PIECE(2, wr, CONV_, LOAD_)                                                                 \
-            GLF_SGB_HALF()                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                \
             GLF_STAMP(2)                                                                                      \
             if (NEXT_) GLF_H8_FRAGS(f, nxt, fo0)                                                              \
@@ -487,7 +430,6 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
             GLF_H8_PIECE(4, wr, CONV_, LOAD_)                                                                 \
             GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
             GLF_H8_PIECE(5, wr, CONV_, LOAD_)                                                                 \
-            GLF_SGB_HALF()                                                                                    \
             { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
             GLF_STAMP(4)                                                                                      \
             __syncthreads();                                                                                  \
@@ -628,162 +570,6 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
 #if defined(GLF_STAMPS) && GLF_STAMPS == 2
         wg_t2 = __builtin_amdgcn_s_memtime();
 #endif
-    }
-
-
-    if (PING && !M16 && !DEEP) {
-        // (every wave of the workgroup executes the same number of barriers, also when it has no tiles at all)
-        const int sw = (lane >> 2) & 3, hh = lane >> 5;
-        const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
-        const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
-        // prologue: tile 0 -> buffer 0 (all waves), tile 1 raw in registers
-        if (ntiles > 0) {
-            advance();
-#pragma unroll
-            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, false, true) }
-            const bool more = ntiles > 1;
-            if (more) advance();
-#pragma unroll
-            for (int pc = 0; pc < 6; ++pc) { GLF_H8_PIECE(pc, 0, true, more) }
-        }
-        __syncthreads();
-        f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l, gb0h, gb1h, gb0l, gb1l, ga0h, ga0l, ga1h, ga1l;
-#define GLF_P8_FRAGS(P, buf_, fo_)                                                                            \
-        {                                                                                                     \
-            const unsigned char* ab_ = smem_s + (buf_) * BUF8 + wm * 64 + (fo_);                              \
-            const unsigned char* bb_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + wn * 64 + (fo_);                  \
-            P##b0h = *reinterpret_cast<const f16x8*>(bb_);                                                    \
-            P##b1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                          \
-            P##a0h = *reinterpret_cast<const f16x8*>(ab_);                                                    \
-            P##a1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                          \
-            if (NP == 3) {                                                                                    \
-                P##a0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                        \
-                P##b0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                        \
-                P##b1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                              \
-                P##a1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                              \
-            } else { P##a0l = P##a0h; P##b0l = P##b0h; P##b1l = P##b1h; P##a1l = P##a1h; }                    \
-        }
-        int cur = 0, wr = 1, spare = 2;          // LDS buffers of tile i, tile i + 1, and the one tile i + 2 will go to
-        // iteration i: STAGE (tile i + 1 raw -> `wr`, loads of tile i + 2, fragments of tile i) | barrier | 24 MFMAs | barrier
-#define GLF_P8_BODY(CONV_, LOAD_)                                                                             \
-        {                                                                                                     \
-            if (LOAD_) advance();                                                                             \
-            GLF_H8_PIECE(0, wr, CONV_, LOAD_) GLF_H8_PIECE(1, wr, CONV_, LOAD_) GLF_H8_PIECE(2, wr, CONV_, LOAD_) \
-            GLF_H8_PIECE(3, wr, CONV_, LOAD_) GLF_H8_PIECE(4, wr, CONV_, LOAD_) GLF_H8_PIECE(5, wr, CONV_, LOAD_) \
-            GLF_P8_FRAGS(f, cur, fo0)                                                                         \
-            GLF_P8_FRAGS(g, cur, fo1)                                                                         \
-            __syncthreads();                                                                                  \
-            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
-            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
-            GLF_ROW3(c00, c01, m00, m01, ga0h, ga0l, gb0h, gb0l, gb1h, gb1l)                                  \
-            GLF_ROW3(c10, c11, m10, m11, ga1h, ga1l, gb0h, gb0l, gb1h, gb1l)                                  \
-            { const int t_ = cur; cur = wr; wr = spare; spare = t_; }                                         \
-            __syncthreads();                                                                                  \
-        }
-        if (wave >= 4) __syncthreads();          // waves 4-7 run half an iteration behind ...
-        int it = 0;
-        for (; it + 2 < ntiles; ++it) GLF_P8_BODY(true, true)
-        if (it + 1 < ntiles) { GLF_P8_BODY(true, false) ++it; }
-        if (it < ntiles) GLF_P8_BODY(false, false)
-        if (wave < 4) __syncthreads();           // ... and waves 0-3 wait for them at the end
-    }
-
-    if (DEEP && !M16 && ntiles > 0) {
-        const int sw = (lane >> 2) & 3, hh = lane >> 5;
-        const int fo0 = (lane & 31) * 64 + (((0 + hh) ^ sw) << 4);
-        const int fo1 = (lane & 31) * 64 + (((2 + hh) ^ sw) << 4);
-        float4 da[2][4], db[2][2];                       // two raw tiles: set S holds tile it + 2 (+ 1) at the top of iteration it
-#define GLF_D8_CONV_A(S, J, buf_)                                                                            \
-        {                                                                                                    \
-            const SplitH s = split4h(da[S][J], sc_a);                                                        \
-            unsigned char* d = smem_s + (buf_) * BUF8 + st_off + J * 64 * 64;                                \
-            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_A8) = s.l;     \
-        }
-#define GLF_D8_CONV_B(S, J, buf_)                                                                            \
-        {                                                                                                    \
-            const SplitH s = split4h(db[S][J], sc_b);                                                        \
-            unsigned char* d = smem_s + (buf_) * BUF8 + 2 * PL_A8 + st_off + J * 64 * 64;                    \
-            *reinterpret_cast<f16x4*>(d) = s.h; if (NP == 3) *reinterpret_cast<f16x4*>(d + PL_B8) = s.l;     \
-        }
-#define GLF_D8_PIECE(pc, S, buf_, conv_, load_)                                                              \
-        switch (pc) {                                                                                        \
-            case 0: if (conv_) GLF_D8_CONV_A(S, 0, buf_) if (load_) da[S][0] = *reinterpret_cast<const float4*>(pa[0]); break; \
-            case 1: if (conv_) GLF_D8_CONV_A(S, 1, buf_) if (load_) da[S][1] = *reinterpret_cast<const float4*>(pa[1]); break; \
-            case 2: if (conv_) GLF_D8_CONV_A(S, 2, buf_) if (load_) da[S][2] = *reinterpret_cast<const float4*>(pa[2]); break; \
-            case 3: if (conv_) GLF_D8_CONV_A(S, 3, buf_) if (load_) da[S][3] = *reinterpret_cast<const float4*>(pa[3]); break; \
-            case 4: if (conv_) GLF_D8_CONV_B(S, 0, buf_) if (load_) db[S][0] = *reinterpret_cast<const float4*>(pb[0]); break; \
-            default: if (conv_) GLF_D8_CONV_B(S, 1, buf_) if (load_) db[S][1] = *reinterpret_cast<const float4*>(pb[1]); break; \
-        }
-        // The tile count is padded to even (ne): an odd count gets one all-zero tile at the end (advance() hands out the zero
-        // page), so that an iteration PAIR is the unit and the set index never depends on run-time parity.
-        // prologue: tiles 0, 1 -> the two sets; tile 0 -> buffer 0 (set 0 refilled with tile 2); tile 1 -> buffer 1 (set 1 <- tile 3)
-        const int ne = (ntiles + 1) & ~1;
-        advance();
-#pragma unroll
-        for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 0, 0, false, true) }
-        advance();
-#pragma unroll
-        for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 1, 0, false, true) }
-        {
-            const bool more = ne > 2;
-            if (more) advance();
-#pragma unroll
-            for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 0, 0, true, more) }
-            if (more) advance();
-#pragma unroll
-            for (int pc = 0; pc < 6; ++pc) { GLF_D8_PIECE(pc, 1, 1, true, more) }
-        }
-        __syncthreads();
-        f16x8 fb0h, fb1h, fb0l, fb1l, fa0h, fa0l, fa1h, fa1l;
-#define GLF_D8_FRAGS(buf_, fo_)                                                                               \
-        {                                                                                                     \
-            const unsigned char* ab_ = smem_s + (buf_) * BUF8 + wm * 64 + (fo_);                              \
-            const unsigned char* bb_ = smem_s + (buf_) * BUF8 + 2 * PL_A8 + wn * 64 + (fo_);                  \
-            fb0h = *reinterpret_cast<const f16x8*>(bb_);                                                      \
-            fb1h = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64);                                            \
-            fa0h = *reinterpret_cast<const f16x8*>(ab_);                                                      \
-            fa1h = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64);                                            \
-            if (NP == 3) {                                                                                    \
-                fa0l = *reinterpret_cast<const f16x8*>(ab_ + PL_A8);                                          \
-                fb0l = *reinterpret_cast<const f16x8*>(bb_ + PL_B8);                                          \
-                fb1l = *reinterpret_cast<const f16x8*>(bb_ + 32 * 64 + PL_B8);                                \
-                fa1l = *reinterpret_cast<const f16x8*>(ab_ + 32 * 64 + PL_A8);                                \
-            } else { fa0l = fa0h; fb0l = fb0h; fb1l = fb1h; fa1l = fa1h; }                                    \
-        }
-        GLF_D8_FRAGS(0, fo0)
-        int cur = 0, nxt = 1, wr = 2;
-        // iteration `it` (set S = it & 1): multiplies tile it, converts tile it + 2 out of set S into `wr`, refills set S with
-        // tile it + 4
-#define GLF_D8_BODY(S, CONV_, LOAD_, NEXT_)                                                                   \
-        {                                                                                                     \
-            if (LOAD_) advance();                                                                             \
-            GLF_D8_PIECE(0, S, wr, CONV_, LOAD_)                                                              \
-            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
-            GLF_D8_PIECE(1, S, wr, CONV_, LOAD_)                                                              \
-            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            GLF_D8_FRAGS(cur, fo1)              /* k-step 1 of this tile into the same registers ... */         \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            GLF_D8_PIECE(2, S, wr, CONV_, LOAD_)  /* ... whose LDS latency these two pieces cover */            \
-            GLF_D8_PIECE(3, S, wr, CONV_, LOAD_)                                                              \
-            GLF_ROW3(c00, c01, m00, m01, fa0h, fa0l, fb0h, fb0l, fb1h, fb1l)                                  \
-            GLF_D8_PIECE(4, S, wr, CONV_, LOAD_)                                                              \
-            GLF_ROW3(c10, c11, m10, m11, fa1h, fa1l, fb0h, fb0l, fb1h, fb1l)                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            if (NEXT_) GLF_D8_FRAGS(nxt, fo0)   /* k-step 0 of the next tile (converted one iteration ago) */   \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            GLF_D8_PIECE(5, S, wr, CONV_, LOAD_)                                                              \
-            { const int t_ = cur; cur = nxt; nxt = wr; wr = t_; }                                             \
-            __syncthreads();                                                                                  \
-        }
-        // steady state while tiles it + 4, it + 5 exist; then two pairs: [convert, convert] (if four tiles are left) and
-        // [fragments only, last] -- compile-time flags throughout (run-time flags or a switch over the remaining count made
-        // hipcc spill hundreds of registers)
-        int it = 0;
-        for (; it + 4 < ne; it += 2) { GLF_D8_BODY(0, true, true, true) GLF_D8_BODY(1, true, true, true) }
-        if (ne - it == 4) { GLF_D8_BODY(0, true, false, true) GLF_D8_BODY(1, true, false, true) }
-        GLF_D8_BODY(0, false, false, true)
-        GLF_D8_BODY(1, false, false, false)
     }
 
     // ---- 16x16x32 variant: accumulators t[i][j] (main) / u[i][j] (mixed), i = 16-row slab, j = 16-column slab of the
@@ -1701,19 +1487,11 @@ int init_gemm_f16s_attrs() {
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-#define SET_ROWS(G, NP_, PA_, PB_) SET_ATTR((gemm_rows_f16s8_kernel<G, NP_, false, PB_, false, false, PA_>), SMEM_ROWS_H8)
+#define SET_ROWS(G, NP_, PA_, PB_) SET_ATTR((gemm_rows_f16s8_kernel<G, NP_, false, PB_, PA_>), SMEM_ROWS_H8)
 #define SET_TN(G, NP_, PA_, PB_) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), SMEM_TN_H) SET_ATTR((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), SMEM_TN_H8)
-#define SET_ALL(G, NP_) SET_ATTR((gemm_rows_f16s8_kernel<G, 3, true, true, false, false, true>), SMEM_ROWS_H8) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
+#define SET_ALL(G, NP_) SET_ATTR((gemm_rows_f16s8_kernel<G, 3, true, true, true>), SMEM_ROWS_H8) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
                         SET_TN(G, NP_, false, false) SET_TN(G, NP_, true, false) SET_TN(G, NP_, false, true) SET_TN(G, NP_, true, true)
     SET_ALL(false, 3) SET_ALL(true, 3) SET_ALL(false, 1) SET_ALL(true, 1)
-#ifdef GLF_EXPERIMENTS      // the measured-and-dropped variants of DESIGN.md section 8 (16x16x32 MFMA, deep prefetch, ping-pong)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, true, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, true, false>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), SMEM_ROWS_H8)
-    SET_ATTR((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), SMEM_ROWS_H8)
-#endif
 #undef SET_ALL
 #undef SET_TN
 #undef SET_ROWS
@@ -1765,42 +1543,26 @@ int launch_rows_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipS
     }
     a.tiles_m = (int)tiles_m;
     dim3 g2((unsigned)(tiles_m * a.tiles_n), 1, grid.z);
-    static const int prio = [] { const char* e = getenv("GLF_SETPRIO"); return e ? (e[0] != '0') : GLF_SETPRIO_DEFAULT; }();
     // tile order: groups of 4 row tiles x all column tiles once there are >= 8 column tiles (more of the streamed operands
     // served from the XCD's L2: +2 % on the N >= 2048 shapes now that the loop is MFMA-bound; -2 % at 4 column tiles)
-    static const int group_m_env = [] { const char* e = getenv("GLF_GROUP_M"); return e ? atoi(e) : -1; }();
-    const int group_m = group_m_env >= 0 ? group_m_env : (a.rect == 0 && a.tiles_n >= 8 ? 4 : 0);
-    a.flags = prio | ((group_m & 0xff) << 8);
+    const int group_m = (a.rect == 0 && a.tiles_n >= 8) ? 4 : 0;
+    a.flags = (group_m & 0xff) << 8;
     const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
 #ifdef GLF_STAMPS
     a.partial = reinterpret_cast<float*>(stamps_buffer());
 #endif
-#define GLF_LAUNCH_ROWS(G, NP_, PA_, PB_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, false, PB_, false, false, PA_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
+#define GLF_LAUNCH_ROWS(G, NP_, PA_, PB_) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<G, NP_, false, PB_, PA_>), g2, dim3(NT8), SMEM_ROWS_H8, s, a)
 #define GLF_ROWS_P(G, NP_)                                                                     \
     { if (pa && pb) GLF_LAUNCH_ROWS(G, NP_, true, true); else if (pa) GLF_LAUNCH_ROWS(G, NP_, true, false); \
       else if (pb) GLF_LAUNCH_ROWS(G, NP_, false, true); else GLF_LAUNCH_ROWS(G, NP_, false, false); }
     // both operands pre-split, three products: the 16x16x32 MFMA form of the loop (same cycles per FLOP as 32x32x16; the chip
     // holds a higher clock on it -- MI355X_MICROARCH.md, DVFS give-back item 7)
-    static const bool m16p = [] { const char* e = getenv("GLF_MFMA16_PRESPLIT"); return e ? e[0] != '0' : GLF_MFMA16_PRESPLIT_DEFAULT; }();
+    static const bool m16p = [] { const char* e = getenv("GLF_MFMA16_PRESPLIT"); return e ? e[0] != '0' : false; }();
     if (nprod == 3 && pa && pb && m16p) {
-        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, true, true, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, true, true, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, true, true, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
+        else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, true, true, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
         return check_launch("gemm_nt(f16x3, 16x16x32, pre-split)");
     }
-#ifdef GLF_EXPERIMENTS
-    static const bool m16 = [] { const char* e = getenv("GLF_MFMA16"); return e ? e[0] != '0' : GLF_MFMA16_DEFAULT; }();
-    static const bool deep = [] { const char* e = getenv("GLF_DEEP"); return e ? e[0] != '0' : GLF_DEEP_DEFAULT; }();
-    static const bool ping = [] { const char* e = getenv("GLF_PING"); return e ? e[0] != '0' : GLF_PING_DEFAULT; }();
-    if (nprod == 3 && !pa && !pb && (ping || deep || m16)) {
-        if (ping) { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-                    else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
-        else if (deep) { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-                         else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, false, false, true>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
-        else { if (gather) hipLaunchKernelGGL((gemm_rows_f16s8_kernel<true, 3, true, false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a);
-               else hipLaunchKernelGGL((gemm_rows_f16s8_kernel<false, 3, true, false>), g2, dim3(NT8), SMEM_ROWS_H8, s, a); }
-        return check_launch("gemm_nt(f16x3, experiment)");
-    }
-#endif
     if (nprod == 3) { if (gather) GLF_ROWS_P(true, 3) else GLF_ROWS_P(false, 3) }
     else { if (gather) GLF_ROWS_P(true, 1) else GLF_ROWS_P(false, 1) }
 #undef GLF_ROWS_P

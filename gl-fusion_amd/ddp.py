@@ -45,7 +45,7 @@ class _Bucket:
 
 class GradAllReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, average: bool = False,
-                 ignore: Optional[Callable[[str], bool]] = default_ignore, process_group=None):
+                 ignore: Optional[Callable[[str], bool]] = default_ignore, process_group=None, in_place: bool = True):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -68,6 +68,21 @@ class GradAllReducer:
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
+        # Gradient producers of the engine (ops.grad_out: conv / linear weight gradients, BatchNorm gamma / beta) write
+        # straight into the parameter's bucket slice, so the hook below finds the gradient already in place and the 736 MB
+        # copy into the buckets is gone.  (Only on a multi-rank job: a single rank keeps private gradient tensors.)
+        self._slots = []
+        if self.world > 1 and in_place:
+            from . import ops
+            for b in self.buckets:
+                for i, p in enumerate(b.params):
+                    ops.register_grad_slot(p, b.flat, b.offsets[i])
+                    self._slots.append(p)
+        self.in_place_elems = 0        # gradient elements found already inside their bucket slice / copied into it (cumulative)
+        self.copied_elems = 0
+        self.overlap_log = []          # per launched bucket: (bucket index, gradients in place when its collective was enqueued, total)
+        self._fired_count = 0
+        self.allreduce_ms = None       # deferred mode: GPU time of the last finalize()'s collectives (timed with events)
         self._handles = []
         # deferred mode (engine.StepGraph): the hooks only copy gradients into the buckets -- work a hipGraph capture can
         # record -- and every collective is launched by finalize(), after backward (after the graph replay), on the current
@@ -91,12 +106,19 @@ class GradAllReducer:
             for e in b.events:
                 cur.wait_event(e)
             b.events = []
+        self.overlap_log.append((self.buckets.index(b), self._fired_count, len(self._where)))
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p: torch.nn.Parameter) -> None:
         b, i = self._where[p]
         off = b.offsets[i]
-        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self._fired_count += 1
+        g = p.grad
+        if not (g.is_contiguous() and g.data_ptr() == b.flat.data_ptr() + off * b.flat.element_size()):
+            b.flat[off:off + p.numel()].copy_(g.reshape(-1))        # produced elsewhere (TPAVI projections, shared parameters ...)
+            self.copied_elems += p.numel()
+        else:
+            self.in_place_elems += p.numel()
         if self.deferred:
             b.fired[i] = True            # the end-of-backward stream join orders the copy before finalize()
             return
@@ -117,11 +139,23 @@ class GradAllReducer:
         skips it exactly as it does on one GPU, so results do not depend on the world size."""
         if self.world == 1:
             return
+        self._fired_count = 0
+        if self._slots:
+            from . import ops
+            ops.release_grad_slots(self._slots)
         if self.deferred:
             # slices of parameters that never fire stay zero (the flat buffer starts zeroed and nothing writes them)
+            ev = None
+            if self.buckets and self.buckets[0].flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
             for b, w in zip(self.buckets, works):
                 w.wait()
+            if ev is not None:
+                ev[1].record()
+                self._last_events = ev
+            for b in self.buckets:
                 if self.average:
                     b.flat.div_(self.world)
                 for i, p in enumerate(b.params):
@@ -129,6 +163,7 @@ class GradAllReducer:
                         off = b.offsets[i]
                         p.grad = b.flat[off:off + p.numel()].view_as(p)
             return
+        self.overlap_log = self.overlap_log[-len(self.buckets):]
         for b in self.buckets:
             if b.work is None:
                 for i, p in enumerate(b.params):
@@ -148,10 +183,23 @@ class GradAllReducer:
             b.fired = [False] * len(b.params)
             b.work = None
 
+    def last_allreduce_ms(self) -> Optional[float]:
+        """GPU time between the first collective's enqueue and the last one's completion in the latest deferred finalize()
+        (synchronises the device)."""
+        ev = getattr(self, "_last_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
+
     def remove(self) -> None:
         for h in self._handles:
             h.remove()
         self._handles = []
+        if self._slots:
+            from . import ops
+            ops.unregister_grad_slots(self._slots)
+            self._slots = []
 
 
 def shard_frames(n_total: int, rank: int, world: int):

@@ -510,6 +510,46 @@ def _tn_split(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
     return int(max(1, min(want, cap, hi)))
 
 
+# ----------------------------------------------------------------------------------------
+# gradient slots: a parameter's gradient produced directly inside its all-reduce bucket (glfusion_amd.ddp)
+# ----------------------------------------------------------------------------------------
+_grad_slots = {}
+
+
+def register_grad_slot(param: torch.Tensor, flat: torch.Tensor, offset: int) -> None:
+    _grad_slots[id(param)] = [weakref.ref(param), flat, int(offset), False]
+
+
+def unregister_grad_slots(params) -> None:
+    for p in params:
+        _grad_slots.pop(id(p), None)
+
+
+def release_grad_slots(params) -> None:
+    """End of a step: every slot may be handed out again."""
+    for p in params:
+        s = _grad_slots.get(id(p))
+        if s is not None:
+            s[3] = False
+
+
+def grad_out(param: Optional[torch.Tensor], shape, device) -> torch.Tensor:
+    """The tensor a backward kernel writes `param`'s gradient into: the parameter's slice of its all-reduce bucket when a
+    GradAllReducer registered one and nobody took it yet this step (a parameter used several times per forward gets ONE
+    in-bucket gradient -- autograd sums the others onto it), a fresh tensor otherwise.  The view is new every time, so
+    autograd's AccumulateGrad can adopt it as .grad without a copy."""
+    if param is not None and _grad_slots:
+        s = _grad_slots.get(id(param))
+        if s is not None and s[0]() is param and not s[3]:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if n == param.numel() and s[1].device == device and not torch.cuda.is_current_stream_capturing():
+                s[3] = True
+                return s[1][s[2]:s[2] + n].view(tuple(shape))
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
 def wgrad_split(rows_o: int, frac: float, cout: int, cin: int, ntap: int, rect: bool) -> int:
     """Reduction slices of a convolution's weight gradient (mirror of conv_api.hip's plan).  A slice is ceil(rows / split) rows
     of EVERY tap's reduction; in rect mode (ASPP: most taps reach only a small rectangle of the map) a tap uses as many slices
@@ -907,7 +947,10 @@ class Conv2dFn(Function):
                 frac = rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask) if rect else 1.0
                 split = wgrad_split(rows_o, frac, cout, cin, ntap, rect)
                 full = mask == (1 << taps) - 1
-                dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
+                if taps == 1 and full and not tn_needs_zero(split):
+                    dwt = grad_out(ctx.weight_ref, (1, cout, cin), x.device)       # a 1x1 weight's gradient is the contraction's output
+                else:
+                    dwt = (zeros if (tn_needs_zero(split) or not full) else torch.empty)(taps, cout, cin, dtype=torch.float32, device=x.device)
                 ok = tn_presplit_ok(cout, cin, cout, cin)
                 am_x = ctx.x_packed[1] if ctx.x_packed is not None else amax_of(x)
                 # dy: the image dgrad made (or one worth making for this kernel alone); x: the image the forward made, if any
@@ -921,7 +964,7 @@ class Conv2dFn(Function):
                 if taps == 1:
                     dw = dwt.view(wshape)
                 else:
-                    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+                    dw = grad_out(ctx.weight_ref, wshape, x.device)
                     check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
             return dw
 
@@ -1226,6 +1269,7 @@ class BatchNormActFn(Function):
         ctx.has_mask = need_mask
         ctx.cfg = (rows, c, relu, training, residual is not None, ldy)
         ctx.packed_grad = bool(packed_grad) and _PREC[0] >= 2
+        ctx.param_refs = (gamma, beta)
         ctx.join = getattr(residual, "_glf_join", None) if residual is not None else None
         _last_bn[0] = (mean, invstd, rows)
         return y
@@ -1239,8 +1283,8 @@ class BatchNormActFn(Function):
         dev = dy.device
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dgamma = grad_out(ctx.param_refs[0], (c,), dev)
+        dbeta = grad_out(ctx.param_refs[1], (c,), dev)
         am = amax_slot(dev)
         # packed: the producing conv reads this gradient only through its dgrad / wgrad contractions -- write it ONCE, as the
         # packed pre-split image they want (scaled by a bound of its maximum the reduction pass provides), instead of fp32

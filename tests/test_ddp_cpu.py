@@ -99,3 +99,26 @@ def test_shard_frames_errors():
     with pytest.raises(ValueError):
         shard_frames(10, 0, 4)
     assert [shard_frames(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+
+
+def test_self_launch_world8(tmp_path):
+    """bench.py's `--gpus N` self-launch plumbing at N = 8 (what the driver's 8-GPU run relies on when it starts the script
+    plainly): eight rank processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, all of them in the collective, rank 0's
+    JSON line relayed, a failing rank turned into a non-zero exit.  CPU + gloo with a toy model (tests/ddp_toy_worker.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "ddp_toy_worker.py")
+    code = f"import sys; sys.path.insert(0, {root!r}); import bench; raise SystemExit(bench.self_launch(8, {worker!r}, ['--tag', 'x']))"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["ranks_in_collective"] == 8 and line["argv"] == ["--tag", "x"]
+    assert line["max_abs_err"] < 1e-4 and line["buckets"] > 2
+    # a rank that dies makes the launcher fail
+    bad = os.path.join(str(tmp_path), "bad.py")
+    open(bad, "w").write("import os, sys\nsys.exit(3 if os.environ['RANK'] == '5' else 0)\n")
+    code = f"import sys; sys.path.insert(0, {root!r}); import bench; raise SystemExit(bench.self_launch(8, {bad!r}, []))"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).returncode != 0
