@@ -114,3 +114,112 @@ class SyntheticPatients:
     def __iter__(self) -> Iterator:
         for p in range(self.n):
             yield {v: self.volume(p, v) for v in self.views}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# host side of the loader: the Dataset contract of datasets/loader.py:190-340 without NIfTI files
+# ------------------------------------------------------------------------------------------------------------
+def crop_offsets(rs, size=(RESIZE, RESIZE), crop=(CROP, CROP)) -> Tuple[int, ...]:
+    """Top-left corner of a RandSpatialCropd(roi_size=crop, random_size=False) window on an image of `size`, drawn from the
+    numpy RandomState `rs` the way MONAI draws it (monai.data.utils.get_random_patch: one `rs.randint(low=0, high=ms - ps + 1)`
+    per spatial dimension, in order, only where the image is larger than the patch) -- so a caller that seeds the transform's
+    RandomState like the reference (loader.py:478-484; MONAI's Randomizable.set_random_state) gets the reference's windows.
+    MONAI is not installed here: restated from its published source, parity unpinned."""
+    return tuple(int(rs.randint(low=0, high=ms - ps + 1)) if ms > ps else 0 for ms, ps in zip(size, crop))
+
+
+class SegPAHDataset:
+    """Seg_PAHDataset (datasets/loader.py:190-340) with the file access factored out: `infos[id]` is a dict with
+    'dataset_name', 'views_images' and 'views_labels', whose per-view entries are raw volumes [H0, W0, T] (numpy / torch) or
+    zero-argument callables returning them (the reference stores NIfTI paths there and calls nibabel, loader.py:233-234).
+    Everything else follows the reference: the train / val / test split of the id list (loader.py:210-217), 4 samples per
+    patient and epoch in train mode (loader.py:289, 335-338), the labelled-frame selection `input_select` (loader.py:429-458:
+    Python's `random` module, so `random.seed` reproduces the reference's picks), the transform chain and the part masks --
+    the last two on the GPU in one kernel (prepare_frames).  Returns (images, masks, index) in the reference's layouts:
+    images [1,112,112] or [1,112,112,T] scaled by 1/255, masks [5,112,112(,T)]."""
+
+    def __init__(self, infos: dict, root=None, is_train: bool = True, data_list=None, set_select=("rmyy",), view_num=("2",),
+                 single_frame: bool = True, clip_length: int = 32, seg_parts: bool = True, require_id: bool = False,
+                 device="cuda", crop_seed=None):
+        import random
+        import numpy as np
+        if len(view_num) != 1:
+            raise ValueError("SegPAHDataset: one view per dataset object, as in the reference (main.py:112-121 builds one per view)")
+        self.is_train, self.view_num, self.single_frame = is_train, list(view_num), single_frame
+        self.clip_length, self.seg_parts, self.require_id, self.device = clip_length, seg_parts, require_id, device
+        self.data_dict = {k: v for k, v in infos.items() if v["dataset_name"] in set_select}          # get_dict, loader.py:416-427
+        self.id_list = list(self.data_dict.keys())
+        if data_list is not None:
+            self.id_list = list(data_list)
+        elif is_train:                                                                             # loader.py:213-217
+            self.train_list = random.sample(self.id_list, int(len(self.id_list) * 0.8))
+            rest = list(set(self.id_list).difference(set(self.train_list)))
+            self.valid_list = random.sample(rest, int(len(rest) * 0.5))
+            self.test_list = list(set(self.id_list).difference(set(self.train_list)).difference(set(self.valid_list)))
+            self.id_list = self.train_list
+        self.R = np.random.RandomState(crop_seed)            # the RandSpatialCropd's own RandomState (MONAI Randomizable)
+
+    def __len__(self) -> int:
+        return len(self.id_list) * 4 if self.is_train else len(self.id_list)
+
+    @staticmethod
+    def _volume(entry):
+        import numpy as np
+        v = entry() if callable(entry) else entry
+        return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+
+    def input_select(self, images: torch.Tensor, masks: torch.Tensor):
+        """loader.py:429-458.  Frames whose label map holds more than 100 labelled pixels are candidates; one is drawn with
+        random.choice; a clip of clip_length - 1 frames around it (start drawn with random.randint) in clip mode."""
+        import random
+        if masks.dim() >= 3:
+            per_frame = masks.sum(dim=(0, 1))
+            cand = torch.nonzero(per_frame > 100).flatten().tolist()
+            if not cand:
+                raise RuntimeError("SegPAHDataset: no labelled frame in this volume (the reference's random.choice raises here too)")
+            index = random.choice(cand)
+            if self.single_frame:
+                return images[:, :, index], masks[..., index], index
+            if masks.shape[-1] == 3:
+                return images[:, :, 1:2].repeat(1, 1, self.clip_length), masks[:, :, 1:2].repeat(1, 1, self.clip_length), index
+            r_index = random.randint(0, index if index < self.clip_length - 1 else self.clip_length - 1)
+            start = index - r_index
+            end = start + self.clip_length - 1
+            return images[:, :, start:end], masks[..., start:end], r_index
+        if self.single_frame:
+            return images, masks, 0
+        return images.unsqueeze(-1).repeat(1, 1, self.clip_length), masks.unsqueeze(-1).repeat(1, 1, self.clip_length), 0
+
+    def __getitem__(self, index: int):
+        view = self.view_num[0]
+        pid = self.id_list[index // 4] if self.is_train else self.id_list[index]
+        entry = self.data_dict[pid]
+        img_e, lab_e = entry["views_images"].get(view), entry["views_labels"].get(view)
+        if img_e is None or lab_e is None:                       # loader.py:262-279: a patient without this view -> zeros
+            shape = (1, CROP, CROP) if self.single_frame else (1, CROP, CROP, self.clip_length)
+            imgs = torch.zeros(shape, device=self.device)
+            masks = torch.zeros((5,) + shape[1:], device=self.device)
+            return (imgs, masks, 0, pid) if self.require_id else (imgs, masks, 0)
+        images, labels = self._volume(img_e).float(), self._volume(lab_e).float()
+        images, labels, idx = self.input_select(images, labels)
+        offs = crop_offsets(self.R) if self.is_train else None
+        frames, masks = prepare_frames(images.to(self.device), labels.to(self.device), view, train=self.is_train, crop_offset=offs)
+        if not self.seg_parts:                                   # loader.py:321: any part -> one foreground channel
+            masks = (masks.sum(dim=1, keepdim=True) > 0).float()
+        if self.single_frame:
+            imgs, masks = frames[0], masks[0]                    # [1,112,112], [5,112,112]
+        else:
+            imgs, masks = frames.permute(1, 2, 3, 0), masks.permute(1, 2, 3, 0)      # [1,112,112,T], [5,112,112,T] (views)
+        return (imgs, masks, idx, pid) if self.require_id else (imgs, masks, idx)
+
+
+def synthetic_infos(views: Sequence[str], n_patients: int, clip_length: int = 40, device="cpu", seed: int = 0, fold: str = "0") -> dict:
+    """An `infos` dict in the reference's shape (np.load('./infos/...npy') of main.py:283) whose volume entries are lazy
+    SyntheticPatients volumes: ids '<fold>_<k>' like the reference's ('0_0', '0_2' = validation, the rest = test, main.py:288-289)."""
+    sp = SyntheticPatients(views, n_patients, clip_length, device=device, seed=seed)
+    infos = {}
+    for k in range(n_patients):
+        infos[f"{fold}_{k}"] = {"dataset_name": "rmyy", "fold": fold,
+                                "views_images": {v: (lambda k=k, v=v: sp.volume(k, v)[0]) for v in views},
+                                "views_labels": {v: (lambda k=k, v=v: sp.volume(k, v)[1]) for v in views}}
+    return infos

@@ -193,6 +193,8 @@ class Trainer:
             if self.print_val:
                 dice = {v: self._calculate_overlap_metrics(masks[v], pred[v].detach())[1] for v in self.test_view}
                 print(f"epoch {epoch}: loss {float(loss):.2f} dice {dice}")
+                if self.config["train"].get("validate_every_epoch", True):
+                    self.validation_and_test(net_root=None, is_fuse=True, raw_data=True)      # main.py:274
             self.save(epoch)
 
     @torch.no_grad()
@@ -236,6 +238,73 @@ class Trainer:
                       + " ".join(f"{d:.4f}" for d in part_dice[v]))
         return result
 
+    @torch.no_grad()
+    def validation_and_test(self, net_root: str = None, is_fuse: bool = True, raw_data: bool = True, infos: dict = None,
+                            val_list=("0_0", "0_2"), test_list=("0_1", "0_3", "0_4", "0_5", "0_6", "0_7", "0_8", "0_9"), first_scored: int = 50):
+        """main.py:279-415.  Two splits of the test infos -- 'Inner-val' (ids 0_0, 0_2) and 'Inner-test' (the other eight) --
+        evaluated clip by clip (batch 1, all frames of the clip as the model's batch, main.py:361-365): per view the BCE-sum loss,
+        pixel accuracy / Dice / precision / specificity / recall over ALL frames of the split and the per-part Dice
+        (main.py:385-407).  net_root None (the call at the end of every training epoch, main.py:274): the current weights, returns
+        the validation Dice averaged over views (main.py:409-410).  With net_root: every checkpoint net_%05d.pth found there is
+        loaded and scored, and the best validation epoch from `first_scored` on is reported (main.py:412-415: epochs 50+).
+        `infos`: the reference loads ./infos/test_infos.npy (NIfTI paths, not shipped); default = synthetic volumes with the same ids."""
+        from .data import SegPAHDataset, synthetic_infos, part_overlap_counts
+        clip = 40 if raw_data else int(self.config["train"].get("clip_length", 40))                       # main.py:307-311
+        if infos is None:
+            infos = synthetic_infos(self.view_num, 10, clip, device="cpu", seed=91)
+        splits = {"Inner-val": [i for i in val_list if i in infos], "Inner-test": [i for i in test_list if i in infos]}
+        sets = {name: {v: SegPAHDataset(infos, is_train=False, data_list=ids, view_num=[v], single_frame=False, clip_length=clip + 1,
+                                        seg_parts=True, device=self.device) for v in self.view_num} for name, ids in splits.items()}
+
+        def score(tag):
+            self.model.eval()
+            report = {}
+            for name, per_view in sets.items():
+                counts = {v: torch.zeros(5, 4, dtype=torch.int64, device=self.device) for v in self.test_view}
+                loss4view = {v: 0.0 for v in self.test_view}
+                for i in range(len(per_view[self.view_num[0]])):
+                    imgs, masks = {}, {}
+                    for v in self.view_num:
+                        img, mask, _ = per_view[v][i]                          # [1,112,112,T], [5,112,112,T]
+                        imgs[v] = img.permute(3, 0, 1, 2).contiguous()         # main.py:361-365: frames become the batch
+                        masks[v] = mask.permute(3, 0, 1, 2).contiguous()
+                    out = self.model(imgs)
+                    pred = out[0] if is_fuse else out[1]
+                    for v in self.test_view:
+                        counts[v] += part_overlap_counts(pred[v], masks[v])
+                        loss4view[v] += float(ops.bce_with_logits_sum(pred[v], masks[v]))
+                res = {}
+                for v in self.test_view:
+                    per_part = all_reduce_counts(counts[v])
+                    res[v] = {"metrics": ops.overlap_metrics_from_counts(per_part.sum(dim=0)), "loss": loss4view[v],
+                              "part_dice": [ops.overlap_metrics_from_counts(per_part[c])[1] for c in range(5)]}
+                    if self.print_val:
+                        m = res[v]["metrics"]
+                        print(f"------Validation Result . {name} for view{v} {tag}------ Loss : {loss4view[v]:.4f} Pixel Acc : {m[0]:.4f} "
+                              f"Dice : {m[1]:.4f} Precision : {m[2]:.4f} Specificity : {m[3]:.4f} Recall : {m[4]:.4f}; part dice "
+                              + " ".join(f"{d:.4f}" for d in res[v]["part_dice"]))
+                report[name] = res
+            val = report["Inner-val"]
+            report["val_dice"] = sum(val[v]["metrics"][1] for v in self.test_view) / max(len(self.test_view), 1)
+            return report
+
+        if net_root is None:
+            self.validation_report = score("")
+            return self.validation_report["val_dice"]
+        dices = []
+        for epoch in range(100):                                                # main.py:317
+            path = os.path.join(net_root, "net_%05d.pth" % epoch)
+            if not os.path.exists(path):
+                break
+            self.model.load_state_dict(torch.load(path, map_location=self.device)["network"], strict=True)
+            dices.append(score(f"(epoch {epoch})")["val_dice"])
+        scored = dices[first_scored:] if len(dices) > first_scored else dices
+        off = first_scored if len(dices) > first_scored else 0
+        best = max(range(len(scored)), key=lambda k: scored[k]) + off if scored else None
+        if self.print_val and best is not None:
+            print(f"best val epoch:{best},best val dice:{dices[best]}")
+        return best, dices
+
     def _calculate_overlap_metrics(self, gt, logits, eps: float = 1e-5):
         """main.py:800-815 on pred = (sigmoid(logits) > 0.5); counters reduced over ranks."""
         counts = all_reduce_counts(ops.overlap_counts(logits, gt))
@@ -249,4 +318,4 @@ class Trainer:
         os.makedirs(d, exist_ok=True)
         torch.save({"network": self.model.state_dict()}, os.path.join(d, "net_%05d.pth" % epoch))
         with open(os.path.join(d, "latest.ckpt"), "w") as f:
-            f.write("%05d" % epoch)                                # main.py:869: zero-padded, as the reference echoes it
+            f.write("%05d\n" % epoch)                              # main.py:869: `echo 00005 > latest.ckpt` (zero-padded, newline)

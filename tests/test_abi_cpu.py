@@ -170,3 +170,40 @@ def test_weights_plan_bookkeeping():
     jobs[4].src = 0x10004                              # packed image source not 16-byte aligned
     assert lib.glf_weights_plan(C.cast(jobs, C.c_void_p), 5, *args) != 0
     assert b"aligned" in lib.glf_last_error()
+
+
+def test_dataset_host_logic_follows_the_loader():
+    """The NIfTI-free Dataset shim (glfusion_amd.data.SegPAHDataset; datasets/loader.py:190-458) on the CPU side: id split,
+    4 samples per patient and epoch in train mode, labelled-frame selection with Python's `random`, and crop windows drawn
+    from a numpy RandomState exactly as MONAI's get_random_patch draws them."""
+    import random
+    import numpy as np
+    import torch
+    from glfusion_amd import data
+    infos = data.synthetic_infos(["4"], 20, clip_length=12, device="cpu", seed=3)
+    infos["x_0"] = dict(infos["0_0"], dataset_name="other")                  # filtered out by set_select
+    random.seed(5)
+    ds = data.SegPAHDataset(infos, is_train=True, view_num=["4"], single_frame=True, device="cpu", crop_seed=11)
+    assert len(ds.train_list) == 16 and len(ds.valid_list) == 2 and len(ds.test_list) == 2 and len(ds) == 64
+    assert not (set(ds.train_list) & set(ds.valid_list)) and not (set(ds.train_list) & set(ds.test_list)) and "x_0" not in ds.id_list
+    ev = data.SegPAHDataset(infos, is_train=False, data_list=["0_1", "0_3"], view_num=["4"], single_frame=False, clip_length=8, device="cpu")
+    assert len(ev) == 2
+    # crop windows: numpy RandomState.randint(0, 144 - 112 + 1) per spatial dimension, in order; nothing drawn where sizes agree
+    rs, rs2 = np.random.RandomState(11), np.random.RandomState(11)
+    assert data.crop_offsets(rs) == (int(rs2.randint(0, 33)), int(rs2.randint(0, 33)))
+    a = data.crop_offsets(rs, size=(144, 144, 40), crop=(112, 112, 40))
+    assert a == (int(rs2.randint(0, 33)), int(rs2.randint(0, 33)), 0) and rs.randint(0, 1 << 30) == rs2.randint(0, 1 << 30)
+    # input_select: only frames with > 100 labelled pixels are candidates; clip mode returns clip_length - 1 frames around one
+    img = torch.zeros(30, 30, 10)
+    lab = torch.zeros(30, 30, 10)
+    lab[:15, :15, 4] = 1.0                                                    # 225 labelled pixels in frame 4 only
+    lab[:5, :5, 7] = 2.0                                                      # 25: below the threshold
+    random.seed(0)
+    f_img, f_lab, idx = ds.input_select(img, lab)
+    assert idx == 4 and tuple(f_lab.shape) == (30, 30) and float(f_lab.sum()) == 225.0
+    random.seed(1)
+    c_img, c_lab, r_idx = ev.input_select(img, lab)
+    random.seed(1)
+    assert random.choice([4]) == 4
+    want_r = random.randint(0, 4)
+    assert r_idx == want_r and c_lab.shape[-1] == min(7, 10 - (4 - want_r)) and float(c_lab[..., want_r].sum()) == 225.0

@@ -90,3 +90,36 @@ def test_eval_harness_vs_oracle():
         assert np.allclose(got[v], whole, atol=1e-4, rtol=0), (v, got[v], whole)            # north_star: Dice within 1e-4
         assert np.allclose(t.eval_report["part_dice"][v], parts, atol=1e-4, rtol=0), (v, t.eval_report["part_dice"][v], parts)
         assert max(parts) > 0.0                                                              # the fixture is not degenerate
+
+
+def test_dataset_shim_and_per_epoch_validation(tmp_path):
+    """SegPAHDataset items come out in the reference's layouts ([1,112,112(,T)] / [5,112,112(,T)], images / 255), and
+    Trainer.validation_and_test (main.py:279-415) scores the Inner-val / Inner-test splits: metrics in [0, 1], five part Dice
+    values per view, the validation Dice as return value; with a checkpoint directory it scores every net_%05d.pth."""
+    import random
+    from glfusion_amd import data
+    from glfusion_amd.engine import Trainer
+    infos = data.synthetic_infos(["4"], 4, clip_length=6, device="cpu", seed=2)
+    random.seed(0)
+    tr = data.SegPAHDataset(infos, is_train=True, data_list=list(infos), view_num=["4"], single_frame=True, device=DEV, crop_seed=1)
+    img, mask, idx = tr[5]
+    assert tuple(img.shape) == (1, 112, 112) and tuple(mask.shape) == (5, 112, 112) and float(img.max()) <= 1.0
+    assert set(mask.unique().tolist()) <= {0.0, 1.0} and float(mask[4].sum()) == 0.0            # view 4 never fills channel 4 (PA)
+    ev = data.SegPAHDataset(infos, is_train=False, data_list=["0_1"], view_num=["4"], single_frame=False, clip_length=5, device=DEV)
+    cimg, cmask, _ = ev[0]
+    assert tuple(cimg.shape[:3]) == (1, 112, 112) and tuple(cmask.shape[:3]) == (5, 112, 112) and cimg.shape[-1] == cmask.shape[-1] <= 4
+    config = {"train": {"view_num": ["4"], "test_view": ["4"], "num_epochs": 1, "batch_size": 2, "iters_per_epoch": 1, "clip_length": 6,
+                        "save_dir": str(tmp_path), "validate_every_epoch": False},
+              "net": {"opt": {"opt_name": "Adam", "lr": 3e-4, "weight_decay": 1e-5}}}
+    t = Trainer(config)
+    random.seed(3)
+    val = t.validation_and_test(net_root=None, infos=infos, val_list=("0_0", "0_2"), test_list=("0_1", "0_3"))
+    rep = t.validation_report
+    assert 0.0 <= val <= 1.0 and set(rep) == {"Inner-val", "Inner-test", "val_dice"}
+    for split in ("Inner-val", "Inner-test"):
+        m = rep[split]["4"]
+        assert all(0.0 <= x <= 1.0 for x in m["metrics"]) and len(m["part_dice"]) == 5 and m["loss"] > 0
+    t.save(0); t.save(1)
+    assert open(tmp_path / "latest.ckpt").read() == "00001\n"
+    best, dices = t.validation_and_test(net_root=str(tmp_path), infos=infos, val_list=("0_0", "0_2"), test_list=("0_1",), first_scored=0)
+    assert len(dices) == 2 and best in (0, 1)
