@@ -63,16 +63,19 @@ def pmc_traffic_per_launch(kernel: str, precision: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
     profiles/summarize_pmc.py) -- PMC counters cannot be collected inside this process, so the figure is the one
     measured on the same workload when the profile was taken; None if the profile is missing."""
-    path = os.path.join(ROOT, "profiles", f"r02_bench_c2_{precision}_pmc_hbm_traffic.csv")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r01_bench_c2_{precision}_pmc_hbm_traffic.csv")
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_c2_{precision}_pmc_hbm_traffic.csv")
+        if os.path.exists(path):
+            break
     try:
         launches, gb = 0, 0.0
         for line in open(path).read().splitlines()[1:]:
             name, rest = line.rsplit(",", 5)[0], line.rsplit(",", 5)[1:]
             # profile names carry every template argument ("gemm_rows_f16s8_kernel<false, 3, false, true, ...>"): the family is
             # every instantiation with the same leading arguments (plain / gather), whatever the operand forms
-            if name.replace(" ", "").startswith(kernel.replace(" ", "").rstrip(">")) and rest[0]:
+            # (since round 3 the family has two tile configurations: the 8-wave f16s8 kernel and the 4-wave f16s4 one)
+            nm = name.replace(" ", "").replace("f16s4_kernel", "f16s8_kernel")
+            if nm.startswith(kernel.replace(" ", "").rstrip(">")) and rest[0]:
                 launches += int(rest[0])
                 gb += float(rest[3])
         if launches:

@@ -21,6 +21,7 @@ from .segmentation import deeplabv3_resnet50_iekd
 _FUSION_STREAMS = os.environ.get("GLF_FUSION_STREAMS", "1") != "0"
 # classifier and centerness head of a view on streams of their own (inside the view's section)
 _HEAD_STREAMS = os.environ.get("GLF_HEAD_STREAMS", "0") != "0"
+_HEAD_ORDER = os.environ.get("GLF_HEAD_ORDER", "0") != "0"
 
 class TPAVIModule(nn.Module):
     """ours.py:770-917.  Built modes: 'dot' (shipped) and 'embedded' (softmax); dimension=3,
@@ -150,6 +151,11 @@ class Global_and_Local(_PerViewNetworks):
             if _HEAD_STREAMS:            # the two heads of a view are independent chains of ~25 kernels each
                 (cls, again), ctr = ops.parallel_sections([lambda: self.classifier[v].forward_nhwc_shared(fa),
                                                            lambda: self.centerness[v].forward_nhwc(fb)])
+            elif _HEAD_ORDER and views.index(v) % 2 == 1:
+                # the views' chains are copies of each other and run in lockstep -- contraction phases and streaming phases line
+                # up across the three streams; every other view evaluates its two (independent) heads in the opposite order
+                ctr = self.centerness[v].forward_nhwc(fb)
+                cls, again = self.classifier[v].forward_nhwc_shared(fa)
             else:
                 cls, again = self.classifier[v].forward_nhwc_shared(fa)     # `again`: the mask_bb call below, same input
                 ctr = self.centerness[v].forward_nhwc(fb)
