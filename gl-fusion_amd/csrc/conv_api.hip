@@ -138,7 +138,8 @@ extern "C" int glf_conv2d_plan(const glf_conv_params* p, int pass, glf_conv_plan
             if (rect) {
                 // slices are cut from the full reduction length (glf_gemm_params.split): a tap uses rows_tap / chunk of them, the
                 // kept taps together ~ kept * frac * split -- scale up so that the launch still fills the chip
-                long long s2 = (long long)((double)plan->split / (frac > 0.02 ? frac : 0.02) + 0.999);
+                long long s2 = (long long)((double)plan->split / (2.0 * (frac > 0.02 ? frac : 0.02)) + 0.999);      // half of split / frac: measured best
+                if (s2 < plan->split) s2 = plan->split;
                 const long long cap = rows_o / 512 > 1 ? rows_o / 512 : 1;
                 if (s2 > cap) s2 = cap;
                 if (s2 > 65535) s2 = 65535;

@@ -22,6 +22,8 @@ _FUSION_STREAMS = os.environ.get("GLF_FUSION_STREAMS", "1") != "0"
 # classifier and centerness head of a view on streams of their own (inside the view's section)
 _HEAD_STREAMS = os.environ.get("GLF_HEAD_STREAMS", "0") != "0"
 _HEAD_ORDER = os.environ.get("GLF_HEAD_ORDER", "0") != "0"
+# the global fusion block beside the views' head sections instead of beside the local block
+_EARLY_GLOBAL = os.environ.get("GLF_EARLY_GLOBAL", "0") != "0"
 
 class TPAVIModule(nn.Module):
     """ours.py:770-917.  Built modes: 'dot' (shipped) and 'embedded' (softmax); dimension=3,
@@ -165,15 +167,41 @@ class Global_and_Local(_PerViewNetworks):
                 fg, gated = ops.axpby(fg, g1, 1.0, -1.0), g2            # f4 * (1 - a) = f4 - f4 * a
             return again, fg, gated, (raw[0] if raw else None)
 
-        secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
-        cls_again = {v: s[0] for v, s in zip(views, secs)}
-        f4_glob = {v: s[1] for v, s in zip(views, secs)}
-        f4_local = {v: s[2] for v, s in zip(views, secs)}
-        # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
-        fusion_jobs = [
-            lambda: self._attend(self.global_attn, ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
-            lambda: self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))]
-        g_out, l_out = ops.parallel_sections(fusion_jobs) if _FUSION_STREAMS else [j() for j in fusion_jobs]
+        if _EARLY_GLOBAL and not self._global_gets_background:
+            # The global fusion block needs only the encoders' outputs: it runs NEXT TO the views' head + gate sections (four
+            # independent chains) instead of after them next to the local block.  The fusion blocks are the part of the step
+            # with the least to overlap with -- two chains of large contractions whose streaming kernels (stack / split /
+            # statistics / LayerNorm tail) ran with nothing but their twin beside them (profiles/r03_timeline_graph_replay.txt).
+            k = 5 if self._third_output_is_f4 else 4
+            enc = ops.parallel_sections([lambda v=v: ops.fan_out(self._encode_view(v, x[v]), k) for v in views])
+
+            def heads_gate(v, parts):
+                ops.use_here(*parts)
+                fa, fb, fc = parts[0], parts[1], parts[2]
+                cls, again = self.classifier[v].forward_nhwc_shared(fa)
+                ctr = self.centerness[v].forward_nhwc(fb)
+                return again, ops.local_gate(cls, ctr, fc, self.center_aware_weight)
+
+            def global_block():
+                fg = [e[3] for e in enc]
+                ops.use_here(*fg)
+                return self._attend(self.global_attn, ops.stack_views(fg))
+            res = ops.parallel_sections([lambda v=v, e=e: heads_gate(v, e) for v, e in zip(views, enc)] + [global_block])
+            g_out = res[-1]
+            cls_again = {v: r[0] for v, r in zip(views, res)}
+            f4_local = {v: r[1] for v, r in zip(views, res)}
+            secs = [(None, None, None, (e[4] if k == 5 else None)) for e in enc]
+            l_out = self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))
+        else:
+            secs = ops.parallel_sections([lambda v=v: view_section(v) for v in views])
+            cls_again = {v: s[0] for v, s in zip(views, secs)}
+            f4_glob = {v: s[1] for v, s in zip(views, secs)}
+            f4_local = {v: s[2] for v, s in zip(views, secs)}
+            # global / local cross-view fusion (ours.py:1819-1830): two independent blocks
+            fusion_jobs = [
+                lambda: self._attend(self.global_attn, ops.stack_views([f4_glob[v] for v in views])),    # [N,V,h,w,C]
+                lambda: self._attend(self.local_attn, ops.stack_views([f4_local[v] for v in views]))]
+            g_out, l_out = ops.parallel_sections(fusion_jobs) if _FUSION_STREAMS else [j() for j in fusion_jobs]
         fused = self._fuse(g_out, l_out)                                                        # ours.py:1833-1834
 
         def head_section(i, v):       # same order per view as the reference: fused mask first, backbone mask second

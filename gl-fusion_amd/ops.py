@@ -558,7 +558,9 @@ def wgrad_split(rows_o: int, frac: float, cout: int, cin: int, ntap: int, rect: 
     centre tap's workgroups ran 3 x (rate 12) to 50 x (rate 24) longer than the corner taps')."""
     split = _tn_split(max(512, int(rows_o * frac)) if rect else rows_o, cout, cin, ntap)
     if rect:
-        s2 = int(split / max(frac, 0.02) + 0.999)
+        # (measured on the 2048 -> 256 ASPP convs, profiles/r03_aspp_wgrad_probe.txt: half of split / frac is the sweet spot --
+        # rate 12: 7 slices 1.01 ms, 14 slices 1.22 ms; rate 24: 19 slices 0.48 ms, 39 slices 0.50 ms, 78 slices 0.57 ms)
+        s2 = max(split, int(split / (2.0 * max(frac, 0.02)) + 0.999))
         split = max(1, min(s2, max(1, rows_o // 512), 65535))
     return split
 
@@ -1627,6 +1629,17 @@ def reset_capture_pools() -> None:
     zero-filled -- INSIDE the capture (a replay then starts from zeroed maxima / statistics like an eager step does)."""
     _amax_pool.clear()
     _stats_pool.clear()
+
+
+def use_here(*tensors) -> None:
+    """Tell the caching allocator that these tensors (allocated on another stream) are read on the CURRENT stream: their
+    memory must not be handed out again before this stream's work on them is done."""
+    if not STREAMS:
+        return
+    cur = torch.cuda.current_stream()
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)
 
 
 def parallel_sections(fns):

@@ -23,17 +23,35 @@ for s, e, n in sel:
     g = 1 if is_gemm(n) else 0
     ev.append((s, 1, g)); ev.append((e, -1, -g))
 ev.sort()
+# which kernels are resident while NO contraction is: sweep again with names
+import collections
+short = lambda n: re.sub(r"\(anonymous namespace\)::|void |<.*|\(.*", "", n)[:40]
+ev2 = []
+for s, e, n in sel:
+    g = 1 if is_gemm(n) else 0
+    ev2.append((s, 1, g, n)); ev2.append((e, -1, -g, n))
+ev2.sort(key=lambda x: (x[0], x[1]))
 t_prev, act, actg = lo, 0, 0
 t_gemm = t_stream = t_idle = 0
 area = 0
-for t, d, g in ev:
+resident = collections.Counter()
+exposed = collections.Counter()
+for t, d, g, n in ev2:
     dt = t - t_prev
     if dt > 0:
         if actg > 0: t_gemm += dt
-        elif act > 0: t_stream += dt
+        elif act > 0:
+            t_stream += dt
+            k = sum(resident.values())
+            for name, c in resident.items():
+                if c > 0:
+                    exposed[short(name)] += dt * c / k
         else: t_idle += dt
         area += dt * act
     act += d; actg += g; t_prev = t
+    resident[n] += d
+    if resident[n] <= 0:
+        del resident[n]
 wall = hi - lo
 ksum = sum(e - s for s, e, n in sel)
 gsum = sum(e - s for s, e, n in sel if is_gemm(n))
@@ -41,3 +59,6 @@ print(f"{nsteps} steps: wall {wall / nsteps / 1e6:.1f} ms/step; kernels {len(sel
       f"(contractions {gsum / nsteps / 1e6:.1f})")
 print(f"  >=1 contraction resident: {t_gemm / nsteps / 1e6:.1f} ms/step; only streaming kernels resident: {t_stream / nsteps / 1e6:.1f}; "
       f"nothing resident: {t_idle / nsteps / 1e6:.1f}; mean concurrent kernels {area / wall:.2f}")
+print("  streaming-only time by resident kernel (ms/step):")
+for k, v in exposed.most_common(14):
+    print(f"    {k:42s} {v / nsteps / 1e6:6.2f}")
