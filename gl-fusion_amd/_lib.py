@@ -120,6 +120,9 @@ class _Lib:
             raise RuntimeError(
                 f"GL-Fusion HIP engine not built: {LIB_PATH} is missing. Build it with "
                 f"`make -C {os.path.join(_PKG, 'csrc')}` (or __graft_entry__.build()). There is no CPU fallback.")
+        # torch first: it brings its own HIP runtime (libamdhip64); loaded after ours, the process would hold two runtimes and the
+        # library's would not see torch's device context ("no ROCm-capable device is detected" from the first glf_* call)
+        import torch  # noqa: F401
         dll = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in self.protos.items():
             fn = getattr(dll, name)          # AttributeError if the .so lacks a declared symbol
