@@ -216,7 +216,12 @@ class Trainer:
                                          int(self.config["train"].get("clip_length", 40)), device=self.device, seed=77)
         counts = {v: torch.zeros(5, 4, dtype=torch.int64, device=self.device) for v in self.test_view}
         loss4view = {v: 0.0 for v in self.test_view}
-        for sample in patients:
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        for k, sample in enumerate(patients):
+            if k % world != rank:                               # every rank scores its own share; counters and losses are summed below
+                continue
             imgs, masks = {}, {}
             for v in self.view_num:
                 imgs[v], masks[v] = _data.prepare_frames(sample[v][0], sample[v][1], v, train=False)
@@ -226,6 +231,10 @@ class Trainer:
                 counts[v] += part_overlap_counts(pred[v], masks[v])
                 loss4view[v] += float(ops.bce_with_logits_sum(pred[v], masks[v]))
         result, part_dice = {}, {}
+        if world > 1:
+            lt = torch.tensor([loss4view[v] for v in self.test_view], dtype=torch.float64, device=self.device)
+            dist.all_reduce(lt)
+            loss4view = {v: float(x) for v, x in zip(self.test_view, lt.tolist())}
         for v in self.test_view:
             per_part = all_reduce_counts(counts[v])
             result[v] = ops.overlap_metrics_from_counts(per_part.sum(dim=0))

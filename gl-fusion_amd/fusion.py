@@ -24,7 +24,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
-from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry, WJ_COPY, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
+from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry, WJ_COPY, stats_slot, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
                   tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, packed_hit, pick, zeros)
 
 
@@ -154,12 +154,20 @@ class TpaviFn(Function):
         wb, pb = pick(zW, weight_packed(zW, wz_w, "w", am_zw) if ok else None, ok)
         am_y = amax_of(y)
         ya, pa = pick(y, act_packed(y, am_y) if ok else None, ok)
-        gemm("nt", ya, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=am_y, amax_b=am_zw, a_packed=pa, b_packed=pb)
+        # train(): the BatchNorm statistics of w come out of the contraction's own epilogue (column sums of w and w^2 in double,
+        # glf_gemm_params.colstats) -- no separate pass over the 1.2 GB tensor
+        fuse_stats = training and split_mode() and nt_presplit_ok(ci, ci, ci) and c % 4 == 0
+        sums = stats_slot(c, dev) if fuse_stats else None
+        gemm("nt", ya, wb, wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, amax_a=am_y, amax_b=am_zw, a_packed=pa, b_packed=pb,
+             colstats=sums)
         ctx.y_packed = (ya, am_y) if (pa and packed_hit(y, am_y) is not None) else None
 
         mean = torch.empty(c, **f32)
         invstd = torch.empty(c, **f32)
-        if training:
+        if fuse_stats:
+            check(lib.glf_bn_stats_from_sums(_p(sums), rows, c, bn_eps, momentum, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
+                                             _stream()), "bn_stats_from_sums")
+        elif training:
             check(lib.glf_bn_stats(_p(wz), c, rows, c, bn_eps, momentum, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
                                    _p(_ws(rows, c, dev)), _stream()), "bn_stats")
         else:

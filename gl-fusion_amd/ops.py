@@ -646,7 +646,13 @@ def packed_hit(t: torch.Tensor, amax: Optional[torch.Tensor]) -> Optional[torch.
     fan_out), or None."""
     hit = getattr(t, "_glf_packed", None)
     if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and hit[2] is amax:
-        return hit[3]
+        pk, made_on = hit[3], (hit[4] if len(hit) > 4 else None)
+        if made_on is not None:
+            cur = torch.cuda.current_stream()
+            if made_on.cuda_stream != cur.cuda_stream:   # a consumer on another side stream: order it behind the split pass
+                cur.wait_stream(made_on)
+                pk.record_stream(cur)
+        return pk
     share = getattr(t, "_glf_pack_share", None)          # the aliases of one fan_out share one image
     if share is not None and share[0] is not None and share[0][0] == t.data_ptr() and share[0][1] is amax:
         pk, made_on = share[0][2], share[0][3]
@@ -717,7 +723,7 @@ def act_packed(t: torch.Tensor, amax: Optional[torch.Tensor], retain: Optional[b
         retain = retain_ok(t.device)
     if retain:
         try:
-            t._glf_packed = (t._version, t.data_ptr(), amax, pk)
+            t._glf_packed = (t._version, t.data_ptr(), amax, pk, torch.cuda.current_stream() if STREAMS else None)
         except AttributeError:
             pass
         share = getattr(t, "_glf_pack_share", None)
