@@ -150,6 +150,9 @@ class Trainer:
         self.loader = SyntheticClips(self.view_num, frames, 112, 112, self.device, seed=1234 + tr.get("global_rank", 0),
                                      length=tr.get("iters_per_epoch", 4))
         self.dense_cyc = bool(tr.get("dense_cyc", False))                      # main.py:228
+        # config['train']['graph']: replay the (cycle-free) training step from one hipGraph instead of issuing ~3 400 launches
+        self.use_graph = bool(tr.get("graph", False))
+        self._graph = None
         self.video_loader = SyntheticClips(self.view_num, int(tr.get("clip_length", 40)), 112, 112, self.device,
                                            seed=4321 + tr.get("global_rank", 0), length=tr.get("iters_per_epoch", 4))
 
@@ -168,8 +171,41 @@ class Trainer:
             total = l if total is None else total + l
         return total
 
+    def _graph_step(self, imgs, masks):
+        """The segmentation step (no cycle term) replayed from ONE hipGraph (StepGraph): the batch is copied into static input
+        buffers, the recorded forward + loss + backward (+ weight-image refresh) runs, Adam updates the parameters in place.
+        Recorded at the first call; the batch shape must not change afterwards."""
+        if self._graph is None:
+            self._static = ({v: torch.empty_like(t) for v, t in imgs.items()}, {v: torch.empty_like(t) for v, t in masks.items()})
+            s_imgs, s_masks = self._static
+            holder = {}
+
+            def core():
+                pred, _, _, _ = self.model(s_imgs)
+                holder["pred"] = pred
+                loss = None
+                for view in self.test_view:
+                    l = ops.bce_with_logits_sum(pred[view], s_masks[view])
+                    loss = l if loss is None else loss + l
+                loss.backward()
+                return loss.detach()
+            for v in imgs:
+                s_imgs[v].copy_(imgs[v]); s_masks[v].copy_(masks[v])
+            self._graph = StepGraph(core, [p for p in self.model.parameters()], warmup=1, reducer=self.reducer if self.reducer.world > 1 else None)
+            self._graph_pred = holder["pred"]
+        s_imgs, s_masks = self._static
+        for v in imgs:
+            if imgs[v].shape != s_imgs[v].shape:
+                raise RuntimeError("glfusion_amd.engine: a graph-replayed step needs batches of one shape (config['train']['graph'] = False for ragged ones)")
+            s_imgs[v].copy_(imgs[v]); s_masks[v].copy_(masks[v])
+        loss = self._graph.replay()
+        self.optimizer.step()
+        return loss, self._graph_pred
+
     def train_step(self, imgs, masks, video=None) -> torch.Tensor:
         """main.py:202-243: forward, sum_v BCE-sum (+ 1e-2 x cycle loss on `video`), backward, Adam step."""
+        if video is None and self.use_graph:
+            return self._graph_step(imgs, masks)
         pred_frames, _, _, _ = self.model(imgs)
         loss = None
         for view in self.test_view:

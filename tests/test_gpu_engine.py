@@ -314,3 +314,38 @@ def test_step_graph_replay_matches_eager_step(prec):
         sg.release()
     finally:
         ops.set_precision("f32")
+
+
+def test_trainer_graph_mode_follows_the_eager_trainer(tmp_path):
+    """config['train']['graph'] = True: Trainer.train_step replays the segmentation step from one hipGraph (static input buffers,
+    fused Adam in place, weight images refreshed inside the recorded work).  Three steps on three different batches against the
+    eager Trainer started from the same weights: same losses (Dropout off), the parameters move together."""
+    from glfusion_amd.engine import Trainer
+    from glfusion_amd import ops
+    ops.set_precision("f16x3")
+    try:
+        def make(graph):
+            cfg = {"train": {"view_num": ["1"], "test_view": ["1"], "num_epochs": 1, "batch_size": 4, "iters_per_epoch": 3, "clip_length": 8,
+                             "save_dir": str(tmp_path), "validate_every_epoch": False, "graph": graph},
+                   "net": {"opt": {"opt_name": "Adam", "lr": 1e-5, "weight_decay": 1e-5}}}
+            torch.manual_seed(0)
+            t = Trainer(cfg)
+            orc.kinkfree_fill(t.model, salt=9)
+            orc.set_dropout(t.model, 0.0)
+            t.model.train()
+            return t
+        eager, graph = make(False), make(True)
+        batches = [eager.loader.batch() for _ in range(3)]
+        le = [float(eager.train_step(i, m)[0]) for i, m in batches]
+        lg = [float(graph.train_step(i, m)[0]) for i, m in batches]
+        assert graph._graph is not None
+        for a, b in zip(le, lg):
+            assert abs(a - b) <= 1e-4 * abs(a), (le, lg)
+        assert len({round(x, 1) for x in lg}) == 3                      # three different batches went through the static buffers
+        pe, pg = dict(eager.model.named_parameters()), dict(graph.model.named_parameters())
+        k = "layer4.1.2.conv3.weight"
+        assert float((pe[k] - pg[k]).norm()) <= 5e-3 * float((pe[k]).norm())
+        moved = float((pg[k] - make(False).model.state_dict()[k]).norm())
+        assert moved > 0.0
+    finally:
+        ops.set_precision("f32")
