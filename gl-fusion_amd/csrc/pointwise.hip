@@ -3,6 +3,7 @@
 // All channels-last; 16-byte accesses wherever the channel count allows; 64-wide wavefront
 // reductions via __shfl_xor.
 #include "glf_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -348,6 +349,22 @@ __global__ __launch_bounds__(256) void copy_frames_kernel(const float4* __restri
         dst[n * dfs + r] = src[n * sfs + r];
     }
 }
+// the same copy that also writes the packed pre-split fp16 image of what it copies (scaled by *amax, an upper bound of the
+// sources' maxima known BEFORE the copy): the stacked fusion-block input is read by contractions only through that image
+__global__ __launch_bounds__(256) void copy_frames_split_kernel(const float4* __restrict__ src, long long sfs, float4* __restrict__ dst,
+                                                                float4* __restrict__ dst_pk, long long dfs, long long inner4, long long total4,
+                                                                const float* __restrict__ amax) {
+    float sc, inv;
+    pow2_scale(amax, sc, inv);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / inner4, r = i - n * inner4;
+        const float4 v = src[n * sfs + r];
+        dst[n * dfs + r] = v;
+        const SplitH sp = split4h(v, sc);
+        const float2 h = __builtin_bit_cast(float2, sp.h), l = __builtin_bit_cast(float2, sp.l);
+        dst_pk[n * dfs + r] = make_float4(h.x, h.y, l.x, l.y);
+    }
+}
 __global__ __launch_bounds__(256) void add_frames_kernel(const float4* __restrict__ a, long long afs, const float4* __restrict__ b, long long bfs,
                                                          float4* __restrict__ dst, long long dfs, long long inner4, long long total4) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
@@ -683,6 +700,19 @@ extern "C" int glf_copy_frames(const float* src, int64_t src_fs, float* dst, int
     hipLaunchKernelGGL(copy_frames_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), reinterpret_cast<const float4*>(src),
                        (long long)(src_fs / 4), reinterpret_cast<float4*>(dst), (long long)(dst_fs / 4), (long long)(inner / 4), total4);
     return glf::check_launch("copy_frames");
+}
+extern "C" int glf_copy_frames_split(const float* src, int64_t src_fs, float* dst, float* dst_packed, int64_t dst_fs, int n, int64_t inner,
+                                     const float* amax, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(src && dst && dst_packed && amax, GLF_ERR_NULL, "copy_frames_split: null argument");
+    GLF_REQUIRE(n > 0 && inner > 0 && (inner % 4) == 0 && (src_fs % 4) == 0 && (dst_fs % 4) == 0, GLF_ERR_BAD_SHAPE,
+                "copy_frames_split: sizes and strides must be positive multiples of 4");
+    GLF_REQUIRE(al16(src) && al16(dst) && al16(dst_packed), GLF_ERR_BAD_SHAPE, "copy_frames_split: alignment");
+    const long long total4 = (long long)n * (inner / 4);
+    hipLaunchKernelGGL(copy_frames_split_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), reinterpret_cast<const float4*>(src),
+                       (long long)(src_fs / 4), reinterpret_cast<float4*>(dst), reinterpret_cast<float4*>(dst_packed), (long long)(dst_fs / 4),
+                       (long long)(inner / 4), total4, amax);
+    return glf::check_launch("copy_frames_split");
 }
 extern "C" int glf_add_frames(const float* a, int64_t a_fs, const float* b, int64_t b_fs, float* dst, int64_t dst_fs,
                               int n, int64_t inner, glf_stream_t s) {

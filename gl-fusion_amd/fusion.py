@@ -29,6 +29,7 @@ from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
+PACKED_TPAVI = os.environ.get("GLF_PACKED_TPAVI", "1") != "0"      # W_z's output gradient handed over as a packed image (train mode)
 
 
 def fused_softmax_ok(ci: int) -> bool:
@@ -203,25 +204,30 @@ class TpaviFn(Function):
         dln_b = torch.empty(c, **f32)
         check(lib.glf_bn_res_ln_bwd(_p(dz), _p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(rmu), _p(rrs),
                                     _p(du), _p(dln_g), _p(dln_b), rows, c, _p(_ws(rows, c, dev)), _stream()), "bn_res_ln_bwd")
-        # BatchNorm3d backward on w
+        # BatchNorm3d backward on w.  Its result dwz has three readers: the weight gradient and the dgrad of W_z -- contractions --
+        # and W_z's bias gradient, the column sum of dwz.  In train mode that sum is ZERO in exact arithmetic (the bias feeds a
+        # BatchNorm: sum_r dwz = -gamma invstd (sum_r xhat) sum(g xhat) / n and sum_r xhat = 0); what fp32 kernels -- the
+        # reference's included -- return there is rounding noise.  So in train mode dwz is written ONCE, as the packed image
+        # the two contractions read (glf_bn_bwd packed_dx), and the bias gradient is returned as the exact value.
+        split = split_mode() and ci % 32 == 0 and c % 32 == 0
         dwz = torch.empty(rows, c, **f32)
         am_dwz_slot = amax_slot(dev)
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
+        dwz_pk = bool(training and split and PACKED_TPAVI and am_dwz_slot is not None and nt_presplit_ok(c, c, c) and tn_presplit_ok(c, ci, c, ci))
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), 0, None, _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), int(dwz_pk), None, _stream()), "bn_bwd")
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)
         dzW = (zeros if tn_needs_zero(sp) else torch.empty)(c, ci, **f32)
         am_dwz, am_q = amax_of(dwz), amax_of(qkv)
         ok = tn_presplit_ok(c, ci, c, ci)
-        dwz_a, pa = pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)       # shared with the NT contraction below
+        dwz_a, pa = (dwz, True) if dwz_pk else pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)       # shared with the NT contraction below
         am_y = ctx.y_packed[1] if ctx.y_packed is not None else amax_of(y)
         yb, pb = pick(y, ctx.y_packed[0] if ctx.y_packed is not None else None, ok)
         gemm("tn", dwz_a, yb, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=sp, amax_a=am_dwz, amax_b=am_y, a_packed=pa, b_packed=pb)
-        dzb = colsum(dwz, rows, c)
-        split = split_mode() and ci % 32 == 0 and c % 32 == 0
+        dzb = zeros(c, device=dev) if dwz_pk else colsum(dwz, rows, c)
         (wz_o,) = ctx.owners
         dy = torch.empty(rows, ci, **f32)
         if split:
@@ -229,7 +235,7 @@ class TpaviFn(Function):
             zWT, am_zw = weight_T(zW, wz_o), amax_of(wz_o)
             ok = nt_presplit_ok(c, c, c)
             wb, pb = pick(zWT, weight_packed(zWT, wz_o, "T2", am_zw), ok)
-            da, pa = pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)
+            da, pa = (dwz, True) if dwz_pk else pick(dwz, act_packed(dwz, am_dwz, True) if ok else None, ok)
             gemm("nt", da, wb, dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci, amax_a=am_dwz, amax_b=am_zw,
                  amax_c=am_dy_slot, a_packed=pa, b_packed=pb)
             del da

@@ -1798,9 +1798,18 @@ class StackViewsFn(Function):
         v = len(xs)
         out = torch.empty(n, v, h, w, c, dtype=torch.float32, device=xs[0].device)
         inner = h * w * c
-        for i, t in enumerate(xs):
-            check(lib.glf_copy_frames(_p(t), inner, _p(out[:, i]), v * inner, n, inner, _stream()), "stack_views")
-        amax_bound(out, xs)
+        amax_bound(out, xs)                  # known BEFORE the copy: the largest of the views' maxima
+        am = getattr(out, "_glf_amax", None)
+        am = am[2] if am is not None else None
+        if am is not None and presplit_ok(out, am) and retain_ok(out.device):
+            # the stack is read by the fusion block's contractions through its packed image only: write it in the same pass
+            pk = torch.empty_like(out)
+            for i, t in enumerate(xs):
+                check(lib.glf_copy_frames_split(_p(t), inner, _p(out[:, i]), _p(pk[:, i]), v * inner, n, inner, _p(am), _stream()), "stack_views")
+            out._glf_packed = (out._version, out.data_ptr(), am, pk, torch.cuda.current_stream() if STREAMS else None)
+        else:
+            for i, t in enumerate(xs):
+                check(lib.glf_copy_frames(_p(t), inner, _p(out[:, i]), v * inner, n, inner, _stream()), "stack_views")
         ctx.cfg = (n, v, h, w, c)
         return out
 

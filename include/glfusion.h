@@ -397,6 +397,11 @@ int glf_gate_bwd(const float* dy, const float* f, const float* cls, int ncls, co
  * dst[n][.] (frame stride dst_fs) = src[n][.] (frame stride src_fs), `inner` floats per frame. */
 int glf_copy_frames(const float* src, int64_t src_fs, float* dst, int64_t dst_fs,
                     int n, int64_t inner, glf_stream_t s);
+/* glf_copy_frames that ALSO writes the packed pre-split image (glf_split_f16_packed's format, same layout as dst) of what it
+ * copies, scaled by *amax -- a device float that already holds an upper bound of max|src| (e.g. glf_amax_combine of the sources'
+ * maxima).  ours.py:1819-1820: the stacked fusion-block input is read once, by the copy, instead of again by a split pass. */
+int glf_copy_frames_split(const float* src, int64_t src_fs, float* dst, float* dst_packed, int64_t dst_fs, int n, int64_t inner,
+                          const float* amax, glf_stream_t s);
 /* dst = a + b with independent frame strides (f4_fusion = f4_global_fusion + f4_local_fusion). */
 int glf_add_frames(const float* a, int64_t a_fs, const float* b, int64_t b_fs, float* dst, int64_t dst_fs,
                    int n, int64_t inner, glf_stream_t s);
