@@ -891,8 +891,12 @@ constexpr int PLANE_T = 32 * RST;
 constexpr int OPER_T = 2 * PLANE_T;
 constexpr size_t SMEM_TN_H = 2 * OPER_T + 32 * sizeof(int);
 
-template <bool GATHER, int NP, bool PA = false, bool PB = false>
+// SMALL: tile 64 x 64 -- every wave owns ONE 32 x 32 accumulator pair instead of a 64 x 64 quadrant, and a staging pass loads
+// 64 columns per operand row instead of 128.  For the layer-1 weight gradients (M, N = 64 ... 256 with one of them 64, K = 193 600
+// rows): on the 128 x 128 tile three of four MFMAs multiplied zero-page columns (64 x 64 x 193 600, nine taps: 0.32 ms at 45 TF).
+template <bool GATHER, int NP, bool PA = false, bool PB = false, bool SMALL = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArgs args) {
+    constexpr int TBM = SMALL ? 64 : BM, TBN = SMALL ? 64 : BN, WT = SMALL ? 32 : 64;
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_accumulate = args.accumulate, p_split = args.split;
     const int p_tiles_n = args.tiles_n;
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     int* vflag = reinterpret_cast<int*>(smem_s + 2 * OPER_T);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % p_tiles_n, tm = bid / p_tiles_n;
     int tap;
@@ -952,33 +956,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     const int r1 = min(pKe, r0 + chunk);
     if (r0 >= r1) return;
 
-    const int c4 = tid & 31, rr = tid >> 5;
-    const int m0 = tm * BM + 4 * c4, n0 = tn * BN + 4 * c4;
+    // staging map: a row of the tile is TBM (= TBN) floats = TBM / 4 threads; NTHREADS / (TBM / 4) rows per pass, 32 rows per tile
+    constexpr int TPR = TBM / 4, RPP = NTHREADS / TPR, NPASS = 32 / RPP;          // 32 threads x 8 rows x 4 passes | 16 x 16 x 2
+    const int c4 = tid % TPR, rr = tid / TPR;
+    const int m0 = tm * TBM + 4 * c4, n0 = tn * TBN + 4 * c4;
     const int m0c = min(m0, pM - 4), n0c = min(n0, pN - 4);
     const int hw = GATHER ? r_h * r_w : 1;
 
     f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
     f32x16 m00 = {0}, m01 = {0}, m10 = {0}, m11 = {0};
-    float4 ra[4], rb[4];
-    int rvalid[4];
+    float4 ra[NPASS], rb[NPASS];
+    int rvalid[NPASS];
 
     // pixel coordinates (inside the tap's rectangle) of this thread's four rows of the NEXT tile to load: set once by
     // division, advanced by 32 rows per tile by carrying (tiles are loaded in order)
-    int gn[4] = {0, 0, 0, 0}, gy[4] = {0, 0, 0, 0}, gx[4] = {0, 0, 0, 0};
+    int gn[NPASS] = {0}, gy[NPASS] = {0}, gx[NPASS] = {0};
     if (GATHER) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + rr + 8 * j;
+        for (int j = 0; j < NPASS; ++j) {
+            const int r = r0 + rr + RPP * j;
             gn[j] = r / hw;
             const int rem = r - gn[j] * hw;
             gy[j] = rem / r_w; gx[j] = rem - gy[j] * r_w;
         }
     }
     auto load_tile = [&](int rbase) __attribute__((always_inline)) {
-        long long src[4], arow[4];
+        long long src[NPASS], arow[NPASS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = rbase + rr + 8 * j;
+        for (int j = 0; j < NPASS; ++j) {
+            const int r = rbase + rr + RPP * j;
             src[j] = -1;
             arow[j] = min(r, r1 - 1);
             if (GATHER) {
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
             rvalid[j] = src[j] >= 0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NPASS; ++j) {
             // rows beyond the slice / in the conv padding and the column overhang read the zero page
             ra[j] = *reinterpret_cast<const float4*>((src[j] >= 0 && m0 < pM ? A + arow[j] * p_lda : p_zero) + m0c);
             rb[j] = *reinterpret_cast<const float4*>((src[j] >= 0 && n0 < pN ? B + src[j] * p_ldb : p_zero) + n0c);
@@ -1007,11 +1013,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     {                                                                                                      \
         const SplitH sa = PA ? unpack4h(ra[J]) : split4h(ra[J], sc_a);                                     \
         const SplitH sb = PB ? unpack4h(rb[J]) : split4h(rb[J], sc_b);                                     \
-        unsigned char* da = As + (rr + 8 * J) * RST + c4 * 8;                                              \
-        unsigned char* db = Bs + (rr + 8 * J) * RST + c4 * 8;                                              \
+        unsigned char* da = As + (rr + RPP * J) * RST + c4 * 8;                                            \
+        unsigned char* db = Bs + (rr + RPP * J) * RST + c4 * 8;                                            \
         *reinterpret_cast<f16x4*>(da) = sa.h; if (NP == 3) *reinterpret_cast<f16x4*>(da + PLANE_T) = sa.l; \
         *reinterpret_cast<f16x4*>(db) = sb.h; if (NP == 3) *reinterpret_cast<f16x4*>(db + PLANE_T) = sb.l; \
-        if (c4 == 0) vflag[rr + 8 * J] = rvalid[J];                                                        \
+        if (c4 == 0) vflag[rr + RPP * J] = rvalid[J];                                                      \
     }
 
     // transposing fragment read (see gemm_bf16s.hip): group g of 16 lanes: columns 16*(g&1).., k half g>>1
@@ -1029,7 +1035,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
 
     load_tile(r0);
     for (int rbase = r0; rbase < r1; rbase += BK) {
-        GLF_HT_STORE(0) GLF_HT_STORE(1) GLF_HT_STORE(2) GLF_HT_STORE(3)
+        GLF_HT_STORE(0) GLF_HT_STORE(1)
+        if constexpr (NPASS == 4) { GLF_HT_STORE(2) GLF_HT_STORE(3) }
         __syncthreads();
         if (rbase + BK < r1) load_tile(rbase + BK);
         const bool any = __ballot(vflag[lane & 31] != 0) != 0ull;
@@ -1038,17 +1045,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
             for (int s = 0; s < 2; ++s) {
                 const unsigned char* ab = As + s * 16 * RST + wm * 2 + tr_off;
                 const unsigned char* bb = Bs + s * 16 * RST + wn * 2 + tr_off;
-                f16x8 b0h, b0l, b1h, b1l;
-                GLF_HTR_FRAG(bb, b0h) GLF_HTR_FRAG(bb + 64, b1h) GLF_HTR_FRAG(bb + PLANE_T, b0l) GLF_HTR_FRAG(bb + 64 + PLANE_T, b1l)
-                {
-                    f16x8 ah, al;
-                    GLF_HTR_FRAG(ab, ah) GLF_HTR_FRAG(ab + PLANE_T, al)
-                    GLF_ROW3(c00, c01, m00, m01, ah, al, b0h, b0l, b1h, b1l)
-                }
-                {
-                    f16x8 ah, al;
-                    GLF_HTR_FRAG(ab + 64, ah) GLF_HTR_FRAG(ab + 64 + PLANE_T, al)
-                    GLF_ROW3(c10, c11, m10, m11, ah, al, b0h, b0l, b1h, b1l)
+                if constexpr (SMALL) {
+                    f16x8 ah, al, bh, bl;
+                    GLF_HTR_FRAG(ab, ah) GLF_HTR_FRAG(ab + PLANE_T, al) GLF_HTR_FRAG(bb, bh) GLF_HTR_FRAG(bb + PLANE_T, bl)
+                    c00 = GLF_MFMA_F16(ah, bh, c00);
+                    if (NP == 3) { m00 = GLF_MFMA_F16(al, bh, m00); m00 = GLF_MFMA_F16(ah, bl, m00); }
+                } else {
+                    f16x8 b0h, b0l, b1h, b1l;
+                    GLF_HTR_FRAG(bb, b0h) GLF_HTR_FRAG(bb + 64, b1h) GLF_HTR_FRAG(bb + PLANE_T, b0l) GLF_HTR_FRAG(bb + 64 + PLANE_T, b1l)
+                    {
+                        f16x8 ah, al;
+                        GLF_HTR_FRAG(ab, ah) GLF_HTR_FRAG(ab + PLANE_T, al)
+                        GLF_ROW3(c00, c01, m00, m01, ah, al, b0h, b0l, b1h, b1l)
+                    }
+                    {
+                        f16x8 ah, al;
+                        GLF_HTR_FRAG(ab + 64, ah) GLF_HTR_FRAG(ab + 64 + PLANE_T, al)
+                        GLF_ROW3(c10, c11, m10, m11, ah, al, b0h, b0l, b1h, b1l)
+                    }
                 }
             }
         }
@@ -1059,11 +1073,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     float cmax = 0.f;
     auto emit = [&](const f32x16& acc, int ti, int tj) {
-        const int col = tn * BN + wn + 32 * tj + col_l;
+        const int col = tn * TBN + wn + 32 * tj + col_l;
         if (col >= pN) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = tm * BM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
+            const int row = tm * TBM + wm + 32 * ti + (r & 3) + 8 * (r >> 2) + row_l;
             if (row < pM) {
                 float* dst = C + (long long)row * ldc_e + col;
                 const float v = p_alpha * acc[r];
@@ -1071,8 +1085,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_f16s_kernel(const GemmArg
             }
         }
     };
-    emit(c00 + m00 * 0x1p-11f, 0, 0); emit(c01 + m01 * 0x1p-11f, 0, 1);
-    emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    emit(c00 + m00 * 0x1p-11f, 0, 0);
+    if constexpr (!SMALL) {
+        emit(c01 + m01 * 0x1p-11f, 0, 1);
+        emit(c10 + m10 * 0x1p-11f, 1, 0); emit(c11 + m11 * 0x1p-11f, 1, 1);
+    }
     if (args.amax_c && !atomic && !args.partial) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
@@ -1488,7 +1505,8 @@ int init_gemm_f16s_attrs() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
 #define SET_ROWS(G, NP_, PA_, PB_) SET_ATTR((gemm_rows_f16s8_kernel<G, NP_, false, PB_, PA_>), SMEM_ROWS_H8)
-#define SET_TN(G, NP_, PA_, PB_) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), SMEM_TN_H) SET_ATTR((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), SMEM_TN_H8)
+#define SET_TN(G, NP_, PA_, PB_) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), SMEM_TN_H) SET_ATTR((gemm_tn_f16s_kernel<G, NP_, PA_, PB_, true>), SMEM_TN_H) \
+                                 SET_ATTR((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), SMEM_TN_H8)
 #define SET_ALL(G, NP_) SET_ATTR((gemm_rows_f16s8_kernel<G, 3, true, true, true>), SMEM_ROWS_H8) SET_ROWS(G, NP_, false, false) SET_ROWS(G, NP_, true, false) SET_ROWS(G, NP_, false, true) SET_ROWS(G, NP_, true, true) \
                         SET_TN(G, NP_, false, false) SET_TN(G, NP_, true, false) SET_TN(G, NP_, false, true) SET_TN(G, NP_, true, true)
     SET_ALL(false, 3) SET_ALL(true, 3) SET_ALL(false, 1) SET_ALL(true, 1)
@@ -1577,14 +1595,21 @@ int launch_tn_f16s(const GemmArgs& a0, dim3 grid, bool gather, int nprod, hipStr
     a.stamps = reinterpret_cast<unsigned long long*>(stamps_buffer());
 #endif
     const bool pa = a.a_presplit != 0, pb = a.b_presplit != 0;
-    const bool wide = a.M > BM;             // 256-wide tiles: re-derive the grid
+    // 64 x 64 tiles when one extent is <= 64 and the other small too (layer 1: 64 x 64, 256 x 64, 64 x 256): no zero-page columns
+    static const bool small_on = [] { const char* e = getenv("GLF_TN_SMALL"); return e ? e[0] != '0' : true; }();
+    const bool small = small_on && (a.M <= 64 || a.N <= 64) && a.M <= 256 && a.N <= 256;
+    const bool wide = !small && a.M > BM;   // 256-wide tiles: re-derive the grid
     dim3 g2 = grid;
     if (wide) {
         a.tiles_m = (a.M + TM8 - 1) / TM8;
         g2 = dim3((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
+    } else if (small) {
+        a.tiles_m = (a.M + 63) / 64; a.tiles_n = (a.N + 63) / 64;
+        g2 = dim3((unsigned)(a.tiles_m * a.tiles_n), grid.y, grid.z);
     }
 #define GLF_LAUNCH_TN(G, NP_, PA_, PB_)                                                                                        \
     { if (wide) hipLaunchKernelGGL((gemm_tn_f16s8_kernel<G, NP_, PA_, PB_>), g2, dim3(NT8), SMEM_TN_H8, s, a);                 \
+      else if (small) hipLaunchKernelGGL((gemm_tn_f16s_kernel<G, NP_, PA_, PB_, true>), g2, dim3(NTHREADS), SMEM_TN_H, s, a);  \
       else hipLaunchKernelGGL((gemm_tn_f16s_kernel<G, NP_, PA_, PB_>), g2, dim3(NTHREADS), SMEM_TN_H, s, a); }
 #define GLF_TN_P(G, NP_)                                                                       \
     { if (pa && pb) GLF_LAUNCH_TN(G, NP_, true, true) else if (pa) GLF_LAUNCH_TN(G, NP_, true, false) \

@@ -194,12 +194,16 @@ def test_bench_self_launch_two_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GLF_DIST_BACKEND="gloo")
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "1",
-                          "--no-exact-f32", "--no-config3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["config"]["ranks_in_collective"] == 2
-    assert line["config"]["global_batch_clips"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    for graph in ("0", "1"):            # the multi-rank default (eager step, collectives overlapped with backward) and the replayed step
+        env = dict(os.environ, GLF_DIST_BACKEND="gloo", GLF_BENCH_GRAPH=graph)
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "1",
+                              "--no-exact-f32", "--no-config3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["config"]["ranks_in_collective"] == 2
+        assert line["config"]["global_batch_clips"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+        assert ("hipGraph" in line["launch"]) == (graph == "1")
+        if graph == "1":
+            assert line["config"]["allreduce_ms_per_step"] is not None
