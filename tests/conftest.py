@@ -51,3 +51,15 @@ def precision(request):
     ops.set_precision(request.param)
     yield request.param
     ops.set_precision("f32")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_engine_state():
+    """Process-wide heuristics of the engine must not leak from one test into the next: the 'device memory is short, stop
+    retaining pre-split images' switch (ops.retain_ok) stays on for the rest of a PROCESS once a large test tripped it."""
+    yield
+    import sys
+    ops = sys.modules.get("glfusion_amd.ops")
+    if ops is not None:
+        ops._retain_off.clear()
+        ops._retain_step.clear()

@@ -194,7 +194,9 @@ def test_bench_self_launch_two_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for graph in ("0", "1"):            # the multi-rank default (eager step, collectives overlapped with backward) and the replayed step
+    # the multi-rank default: the eager step, collectives overlapped with backward (what the driver's multi-GPU run executes).  The
+    # replayed step under a multi-rank reducer (GLF_BENCH_GRAPH=1) is covered by test_two_ranks_match_single_process.
+    for graph in ("0",):
         env = dict(os.environ, GLF_DIST_BACKEND="gloo", GLF_BENCH_GRAPH=graph)
         env.pop("WORLD_SIZE", None)
         env.pop("RANK", None)

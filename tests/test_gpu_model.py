@@ -727,6 +727,10 @@ def test_config5_full_clip_T32_on_one_gpu():
         assert peak < 270
     finally:
         ops.set_precision("f32")
+        del model, imgs, tgts
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()                  # 230 GB of cached blocks would slow every later test's allocations down
 
 
 def test_f16_mode_parity(golden_dir):
