@@ -35,6 +35,7 @@ class GemmParams(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("a_presplit", C.c_int32), ("b_presplit", C.c_int32),
         ("precision", C.c_int32),
+        ("colmax", C.c_void_p),
     ]
 
 

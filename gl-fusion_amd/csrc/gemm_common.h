@@ -22,6 +22,7 @@ struct GemmArgs {
     const float* zeros;                         // f16x3 only: device page of ZERO_PAGE_FLOATS zeros
     float* amax_c;                              // f16x3 only: receives max(*amax_c, max|C written|) (null = not wanted)
     double* colstats;                           // f16x3 NT only: [2][N] += column sums of C and of C^2 (null = not wanted)
+    float* colmax;                              // f16x3 NT only, with colstats: [N] = max(colmax, column maxima of |C|) (null = not wanted)
     float* partial;                             // TN only: partial-sum slabs [batch*split][kept taps][M][N] (null = atomics into C)
     unsigned long long* stamps;                 // diagnostic builds (-DGLF_STAMPS) only
     int a_presplit, b_presplit;                 // f16x3 / f16 kernels: the operand pointer is the packed pre-split image (glf_split_f16_packed)
@@ -186,7 +187,7 @@ GemmArgs make_args(const float* A, const float* B, const float* bias, float* C, 
     a.alpha = p->alpha; a.accumulate = p->accumulate; a.split = p->split < 1 ? 1 : p->split;
     a.tiles_m = (p->M + BM - 1) / BM; a.tiles_n = (p->N + BN - 1) / BN;
     a.vec_a = 0; a.vec_b = 0; a.rect = 0;
-    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.partial = nullptr; a.flags = 0; a.stamps = nullptr; a.a_presplit = p->a_presplit; a.b_presplit = p->b_presplit;
+    a.amax_a = p->amax_a; a.amax_b = p->amax_b; a.zeros = nullptr; a.amax_c = p->amax_c; a.colstats = p->colstats; a.colmax = p->colstats ? p->colmax : nullptr; a.partial = nullptr; a.flags = 0; a.stamps = nullptr; a.a_presplit = p->a_presplit; a.b_presplit = p->b_presplit;
     return a;
 }
 

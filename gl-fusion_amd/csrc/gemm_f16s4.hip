@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT4, 2) void gemm_rows_f16s4_kernel(const GemmArgs 
         const int c4 = 4 * (lane & 15), r0 = lane >> 4;
         const int col = tn * BN + wn + c4;
         double cs[4] = {0.0, 0.0, 0.0, 0.0}, cq[4] = {0.0, 0.0, 0.0, 0.0};
+        float cx[4] = {0.f, 0.f, 0.f, 0.f};          // column maxima of |C| (args.colmax)
         if (col < pN) {
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (p_bias) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(NT4, 2) void gemm_rows_f16s4_kernel(const GemmArgs 
                 cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 if (p_colstats) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const double vd = (double)v[j]; cs[j] += vd; cq[j] = fma(vd, vd, cq[j]); }
+                    for (int j = 0; j < 4; ++j) { const double vd = (double)v[j]; cs[j] += vd; cq[j] = fma(vd, vd, cq[j]); cx[j] = fmaxf(cx[j], fabsf(v[j])); }
                 }
             }
         }
@@ -417,24 +418,29 @@ __global__ __launch_bounds__(NT4, 2) void gemm_rows_f16s4_kernel(const GemmArgs 
             // addresses: 3 025 per address on a 193 600-row layer-1 conv output -- ~150 us of serialised atomics behind a 60 us
             // contraction (profiles/r03_colstats_atomics.txt).
             double* st = args.colstats;
-            double* fold = reinterpret_cast<double*>(tile);              // [64 columns][2]
+            double* fold = reinterpret_cast<double*>(tile);              // [64 columns][3]: sum, sum of squares, maximum
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 cs[j] += __shfl_xor(cs[j], 16, 64); cq[j] += __shfl_xor(cq[j], 16, 64);
                 cs[j] += __shfl_xor(cs[j], 32, 64); cq[j] += __shfl_xor(cq[j], 32, 64);
-                if (lane < 16) { fold[2 * (c4 + j)] = cs[j]; fold[2 * (c4 + j) + 1] = cq[j]; }
+                cx[j] = fmaxf(cx[j], __shfl_xor(cx[j], 16, 64)); cx[j] = fmaxf(cx[j], __shfl_xor(cx[j], 32, 64));
+                if (lane < 16) { fold[3 * (c4 + j)] = cs[j]; fold[3 * (c4 + j) + 1] = cq[j]; fold[3 * (c4 + j) + 2] = (double)cx[j]; }
             }
             __syncthreads();
             if (wm == 0) {                                               // waves 0 / 1: the two column halves of the tile
                 const int cl = lane;                                     // column within the wave's 64
                 double s = 0.0, q = 0.0;
+                float mx = 0.f;
 #pragma unroll
                 for (int w = 0; w < WAVE_ROWS; ++w) {
                     const double* f = reinterpret_cast<const double*>(reinterpret_cast<const float*>(smem_s) + (2 * w + (wave & 1)) * (64 * 64));
-                    s += f[2 * cl]; q += f[2 * cl + 1];
+                    s += f[3 * cl]; q += f[3 * cl + 1]; mx = fmaxf(mx, (float)f[3 * cl + 2]);
                 }
                 const int cg = tn * BN + wn + cl;
-                if (cg < pN) { atomicAdd(st + cg, s); atomicAdd(st + pN + cg, q); }
+                if (cg < pN) {
+                    atomicAdd(st + cg, s); atomicAdd(st + pN + cg, q);
+                    if (args.colmax && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(args.colmax + cg), __float_as_uint(mx));
+                }
             }
         }
     } else {

@@ -376,16 +376,22 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restr
                                                             float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out, float* rmean, float* rvar,
                                                             long long* nbt, long long total4, int c4, int relu, float* __restrict__ amax_out,
-                                                            unsigned char* __restrict__ mask) {
+                                                            unsigned char* __restrict__ mask, const float* __restrict__ colmax) {
+    // colmax != null: y is written as the packed pre-split fp16 image (glf_split_f16_packed's format), scaled with an upper
+    // bound of max |y| that every workgroup derives from the per-channel maxima of |x| BEFORE writing anything:
+    //   |y_c| <= |gamma_c| invstd_c (max|x_c| + |mean_c|) + |beta_c|        (workgroup 0 stores the bound to *amax_out)
     extern __shared__ __attribute__((aligned(16))) float s_coef[];       // [2][c]: mean, invstd
+    __shared__ float s_bound[4];
     float* s_mean = s_coef;
     float* s_is = s_coef + c;
+    float bound = 0.f;
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
         const double m = sums[ch] / rows;
         double var = sums[c + ch] / rows - m * m;
         if (var < 0) var = 0;
         const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
         s_mean[ch] = mf; s_is[ch] = isf;
+        if (colmax) bound = fmaxf(bound, fabsf(gamma[ch]) * isf * (colmax[ch] + fabsf(mf)) + fabsf(beta[ch]));
         if (blockIdx.x == 0) {
             mean_out[ch] = mf; invstd_out[ch] = isf;
             if (rmean) {
@@ -396,7 +402,18 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restr
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    float sc = 1.f, sc_inv = 1.f;
+    if (colmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+        if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = bound;
+    }
     __syncthreads();
+    if (colmax) {
+        bound = 1.0001f * fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3]));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *amax_out = bound;
+        pow2_scale(&bound, sc, sc_inv);
+    }
     float am = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
@@ -414,10 +431,16 @@ __global__ __launch_bounds__(256) void bn_apply_sums_kernel(const float* __restr
         }
         if (mask) mask[i] = (unsigned char)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (colmax) {
+            const SplitH sp = split4h(o, sc);
+            const float2 h = __builtin_bit_cast(float2, sp.h), l = __builtin_bit_cast(float2, sp.l);
+            o = make_float4(h.x, h.y, l.x, l.y);
+        } else {
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
         *reinterpret_cast<float4*>(y + r * ldy + cc) = o;
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (amax_out) block_amax(am, amax_out);
+    if (amax_out && !colmax) block_amax(am, amax_out);
 }
 
 // dx = gamma*invstd*(dy' - [sum_dy/n + xhat*sum_dyx/n]) ; dres = dy'
@@ -669,9 +692,10 @@ extern "C" int glf_bn_apply(const float* x, int ldx, const float* residual, int 
 extern "C" int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
                                       int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
                                       float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                      int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s) {
+                                      int relu, float* amax_out, uint8_t* relu_mask, const float* colmax, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y && sums && mean && invstd && gamma && beta, GLF_ERR_NULL, "bn_apply_from_sums: null argument");
+    GLF_REQUIRE(!colmax || (amax_out && !residual && y != x), GLF_ERR_BAD_SHAPE, "bn_apply_from_sums: the packed output (colmax) needs amax_out, no residual and y != x");
     GLF_REQUIRE(rows > 0, GLF_ERR_BAD_SHAPE, "bn_apply_from_sums: rows must be > 0");
     REQ_C4(c); REQ_AL(x, "x"); REQ_AL(y, "y"); REQ_LD(ldx, "ldx"); REQ_LD(ldy, "ldy");
     GLF_REQUIRE(c <= APPLY_MAX_C, GLF_ERR_UNSUPPORTED, "bn_apply_from_sums: C must be <= %d (use glf_bn_stats_from_sums + glf_bn_apply)", APPLY_MAX_C);
@@ -680,7 +704,7 @@ extern "C" int glf_bn_apply_from_sums(const float* x, int ldx, const float* resi
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_apply_sums_kernel, dim3(stream_grid(total4, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s), x, ldx, residual, ldr, y, ldy, sums, rows, c,
                        eps, momentum, gamma, beta, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked),
-                       total4, c / 4, relu, amax_out, relu_mask);
+                       total4, c / 4, relu, amax_out, relu_mask, colmax);
     return glf::check_launch("bn_apply_from_sums");
 }
 

@@ -43,8 +43,8 @@ class Conv2d(nn.Conv2d):
 
 
 class BatchNorm2d(nn.BatchNorm2d):
-    def forward_nhwc(self, x, relu: bool = False, residual=None, sums=None, packed_grad: bool = False):
-        return ops.batch_norm_act(x, self, relu, residual, sums, packed_grad)
+    def forward_nhwc(self, x, relu: bool = False, residual=None, sums=None, packed_grad: bool = False, packed_out: bool = False):
+        return ops.batch_norm_act(x, self, relu, residual, sums, packed_grad, packed_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.from_nhwc(self.forward_nhwc(ops.to_nhwc(x)))
@@ -83,10 +83,12 @@ class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
 FUSE_BN_STATS = os.environ.get("GLF_FUSE_BN_STATS", "1") != "0"
 
 
-def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
+def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None, consumer: Conv2d = None):
     """conv -> BatchNorm (train or eval) -> (+residual) -> (ReLU) on NHWC tensors.  In train() the batch statistics
     (sum x, sum x^2 per channel) are accumulated by the conv's own epilogue where the kernel supports it, which saves the
-    separate statistics pass over the conv output."""
+    separate statistics pass over the conv output.
+    consumer: the convolution that is the ONLY reader of the result (the next conv inside a bottleneck).  Where its kernels
+    take a packed pre-split input, the result is written once in that form and has no fp32 copy: do not read it as floats."""
     training = bn.training or bn.running_mean is None
     stem = conv.in_channels == 1 and conv.kernel_size == (7, 7)
     # the conv output's gradient has ONE consumer, this conv's backward: BatchNorm backward may hand it over as a packed image
@@ -95,5 +97,8 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None):
         stride, pad, dil = conv._geom()
         if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2]):
             sums = ops.stats_slot(conv.out_channels, x.device)
-            return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums, packed_grad=pg)
+            po = consumer is not None and residual is None and ops.takes_packed_input(consumer.weight)
+            if po:
+                sums._glf_colmax = ops.colmax_slot(conv.out_channels, x.device)     # bounds the BatchNorm output before it exists
+            return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums, packed_grad=pg, packed_out=po)
     return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual, packed_grad=pg)

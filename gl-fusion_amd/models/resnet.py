@@ -36,8 +36,8 @@ class Bottleneck(nn.Module):
         if self.downsample is None and x is not xs:
             ops.join_gradients(x, xs)     # identity shortcut: conv1's dgrad accumulates onto the shortcut's gradient
         idn = xs if self.downsample is None else conv_bn_act(xs, self.downsample[0], self.downsample[1], relu=False)
-        out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        out = conv_bn_act(x, self.conv1, self.bn1, relu=True, consumer=self.conv2)      # inner activations: one reader each
+        out = conv_bn_act(out, self.conv2, self.bn2, relu=True, consumer=self.conv3)
         return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=idn)      # relu(bn3(.) + identity)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

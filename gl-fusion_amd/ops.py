@@ -146,7 +146,8 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
          bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False,
          split: int = 1, rect: bool = False, amax_a: Optional[torch.Tensor] = None,
          amax_b: Optional[torch.Tensor] = None, amax_c: Optional[torch.Tensor] = None,
-         colstats: Optional[torch.Tensor] = None, a_packed: bool = False, b_packed: bool = False) -> None:
+         colstats: Optional[torch.Tensor] = None, a_packed: bool = False, b_packed: bool = False,
+         colmax: Optional[torch.Tensor] = None) -> None:
     """mode in {'nt','nn','tn'}; geo = (n_img, hs, ws, hd, wd, kh, kw, stride, pad, dil).
     amax_a / amax_b: device scalars bounding max|A| / max|B| (f16x3 precision only; None = measured by the library);
     amax_c: a slot from amax_slot() that receives max|C written| (ignored by rect / split > 1 / non-f16x3 calls -- pass
@@ -163,6 +164,7 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: in
     p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
     p.amax_a, p.amax_b, p.amax_c = _p(amax_a), _p(amax_b), _p(amax_c)
     p.colstats = _p(colstats)                  # zero-filled float64 [2, N]: column sums of C and C^2 (f16x3 NT only)
+    p.colmax = _p(colmax)                      # zero-filled float32 [N]: column maxima of |C| (with colstats)
     p.precision = _PREC[0] + 1
     p.a_presplit, p.b_presplit = int(a_packed), int(b_packed)
     ws = None
@@ -453,6 +455,20 @@ def stats_slot(c: int, dev) -> torch.Tensor:
     i = pool[1]
     pool[1] = i + need
     return pool[0][i:i + need].view(2, c)
+
+
+_colmax_pool: dict = {}
+
+
+def colmax_slot(c: int, dev) -> torch.Tensor:
+    """A zeroed float32 [c] for a contraction's per-column maxima (glf_gemm_params.colmax), pooled like stats_slot."""
+    key = torch.cuda.current_stream().cuda_stream
+    pool = _colmax_pool.get(key)
+    if pool is None or pool[1] + c > pool[0].numel() or pool[0].device != dev:
+        pool = _colmax_pool[key] = [zeros(max(1 << 16, c), dtype=torch.float32, device=dev), 0]
+    i = pool[1]
+    pool[1] = i + c
+    return pool[0][i:i + c]
 
 
 def amax_bound(t: torch.Tensor, srcs: Sequence[Optional[torch.Tensor]], scale: float = 1.0, sum_: bool = False) -> None:
@@ -874,14 +890,17 @@ class Conv2dFn(Function):
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         am_w, am_x = amax_of(weight), amax_of(x)
         ok = nt_presplit_ok(cin, cin, cin)
+        x_pk = packed_only(x)                # the producing BatchNorm wrote the activation as a packed image (no fp32 form exists)
+        if x_pk and not (ok and am_x is not None and takes_packed_input(weight)):
+            raise RuntimeError("glfusion_amd: a packed-only activation reached a convolution that cannot consume it")
         ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or packed_hit(x, am_x) is not None)
-        xa, pa = pick(x, act_packed(x, am_x) if ok_x else None, ok_x)
+        xa, pa = (x, True) if x_pk else pick(x, act_packed(x, am_x) if ok_x else None, ok_x)
         wb, pb = pick(wt, weight_packed(wt, weight, "w", am_w) if ok else None, ok)
         gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
              taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
-             amax_a=am_x, amax_b=am_w, colstats=colstats, a_packed=pa, b_packed=pb)
+             amax_a=am_x, amax_b=am_w, colstats=colstats, colmax=getattr(colstats, "_glf_colmax", None), a_packed=pa, b_packed=pb)
         ctx.save_for_backward(x, wt)
-        ctx.x_packed = (xa, am_x) if (pa and packed_hit(x, am_x) is not None) else None      # retained: the weight gradient reads the same image
+        ctx.x_packed = (xa, am_x) if (pa and (x_pk or packed_hit(x, am_x) is not None)) else None      # retained: the weight gradient reads the same image
         ctx.join = getattr(x, "_glf_join", None) if plain else None
         ctx.weight_ref = weight            # for the cached [tap][Cin][Cout] layout of the split-bf16 dgrad
         ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
@@ -1236,7 +1255,7 @@ RELU_MASK_BYTES = os.environ.get("GLF_RELU_MASK_BYTES", "1") != "0"       # BN(+
 class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool,
-                momentum: float, eps: float, relu: bool, sums=None, packed_grad: bool = False):
+                momentum: float, eps: float, relu: bool, sums=None, packed_grad: bool = False, packed_out: bool = False):
         _chk(x, "bn input"); _chk(gamma, "bn weight"); _chk(beta, "bn bias")
         x = _contig(x)
         c = x.shape[-1]
@@ -1259,19 +1278,27 @@ class BatchNormActFn(Function):
             check(lib.glf_bn_eval_coeffs(_p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
         if residual is not None:
             residual = _contig(_chk(residual, "bn residual"))
+        # packed_out: the only reader is a convolution that takes its input as a packed pre-split image -- write that, once,
+        # scaled by a bound of max |y| derived from the conv epilogue's per-channel maxima (no fp32 y, no split pass)
+        colmax = getattr(sums, "_glf_colmax", None) if sums is not None else None
+        packed = (bool(packed_out) and fused_stats and residual is None and colmax is not None and _PREC[0] >= 2
+                  and PACKED_ACTS and _OUT_VIEW[0] is None)
         y, ldy, shared = _take_out(x.shape, dev)
         am = shared if shared is not None else amax_slot(dev)
+        packed = packed and am is not None
         # relu + residual: the backward needs the sign of the forward output -- kept as one byte per four channels instead of y
         need_mask = relu and residual is not None and torch.is_grad_enabled() and RELU_MASK_BYTES
         mask = torch.empty(rows * (c // 4), dtype=torch.uint8, device=dev) if need_mask else None
         if fused_stats:
             check(lib.glf_bn_apply_from_sums(_p(x), c, _p(residual), c, _p(y), ldy, _p(sums), rows, c, eps, momentum, _p(gamma), _p(beta),
                                              _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt), int(relu), _p(am),
-                                             _p(mask), _stream()), "bn_apply_from_sums")
+                                             _p(mask), _p(colmax) if packed else None, _stream()), "bn_apply_from_sums")
         else:
             check(lib.glf_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta), rows, c,
                                    int(relu), _p(am), _p(mask), _stream()), "bn_apply")
         set_amax(y, am)
+        if packed:
+            y._glf_packed_only = True
         # without a residual the ReLU mask is recomputed from x in backward (sign of the same expression): y is not kept
         ctx.save_for_backward(x, mask if need_mask else (y if (relu and residual is not None) else None), mean, invstd, gamma, beta if relu else None)
         ctx.has_mask = need_mask
@@ -1307,7 +1334,7 @@ class BatchNormActFn(Function):
             dx._glf_packed_only = True
         if ctx.join is not None and dres is not None:
             ctx.join.parked, dres = dres, None       # handed to the block's first conv, whose dgrad accumulates onto it
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 # When a list, every train-mode batch_norm_act call appends (module, batch mean, batch invstd, rows): enough to
@@ -1338,11 +1365,25 @@ def takes_packed_grad(weight: torch.Tensor) -> bool:
     return cout % 32 == 0 and nt_presplit_ok(cout, cout, cout) and tn_presplit_ok(cout, cin, cout, cin)
 
 
+# BatchNorm forward hands an activation whose only reader is a convolution to it as a packed pre-split image
+PACKED_ACTS = os.environ.get("GLF_PACKED_ACTS", "1") != "0"
+
+
+def takes_packed_input(weight: torch.Tensor) -> bool:
+    """True when Conv2dFn can consume its INPUT as a packed-only image: its forward (NT, K = Cin) and its weight gradient
+    (TN, N = Cin) both run on the aligned split-fp16 kernels."""
+    if not PACKED_ACTS or _PREC[0] < 2 or not PRESPLIT:
+        return False
+    cout, cin = weight.shape[0], weight.shape[1]
+    return cin % 32 == 0 and nt_presplit_ok(cin, cin, cin) and tn_presplit_ok(cout, cin, cout, cin)
+
+
 def packed_only(t: torch.Tensor) -> bool:
     return bool(getattr(t, "_glf_packed_only", False))
 
 
-def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None, packed_grad: bool = False):
+def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, residual=None, sums=None, packed_grad: bool = False,
+                   packed_out: bool = False):
     """nn.BatchNorm{2,3}d semantics (train: batch stats + running update; eval: running stats),
     optionally fused with a residual add and ReLU."""
     training = bn.training or bn.running_mean is None
@@ -1357,7 +1398,7 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
                              bn.running_mean if (track or not training) else None,
                              bn.running_var if (track or not training) else None,
                              bn.num_batches_tracked if track else None,
-                             training, momentum, float(bn.eps), relu, sums if training else None, packed_grad)
+                             training, momentum, float(bn.eps), relu, sums if training else None, packed_grad, packed_out)
     if BN_TAP is not None and track:
         BN_TAP.append((bn,) + _last_bn[0])
     return y
@@ -1635,6 +1676,7 @@ def reset_capture_pools() -> None:
     zero-filled -- INSIDE the capture (a replay then starts from zeroed maxima / statistics like an eager step does)."""
     _amax_pool.clear()
     _stats_pool.clear()
+    _colmax_pool.clear()
 
 
 def use_here(*tensors) -> None:

@@ -139,6 +139,10 @@ typedef struct {
     int32_t precision;          /* contraction precision of THIS call: 0 = the process default (glf_set_precision), */
                                 /* 1 = exact fp32, 2 = split-bf16 x6, 3 = split-fp16 x3, 4 = fp16 x1 (= 1 + the modes of */
                                 /* glf_set_precision).  Two models with different precisions can share a process.   */
+    float* colmax;              /* with colstats, may be NULL: DEVICE floats [N], zero-filled by the caller; the epilogue   */
+                                /* raises colmax[n] to the largest |C[m][n]| it stores -- with the batch statistics it bounds */
+                                /* the BatchNorm OUTPUT's maximum before that output exists (glf_bn_apply_from_sums         */
+                                /* packed_y: the activation written once, as the packed image its consumer reads)           */
 } glf_gemm_params;
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
@@ -331,11 +335,18 @@ int glf_bn_apply(const float* x, int ldx, const float* residual, int ldr, float*
 /* glf_bn_stats_from_sums + glf_bn_apply in ONE launch (train mode, statistics from a contraction's colstats): every
  * workgroup finishes mean / invstd for all channels in LDS, workgroup 0 writes them to mean / invstd (for the backward pass)
  * and updates running_mean / running_var / num_batches_tracked (all three may be NULL).  Bit-identical to the two calls.
- * C <= 4096. */
+ * C <= 4096.
+ * colmax (may be NULL; precision 3 / 4 callers): the per-channel maxima of |x| the same contraction epilogue left
+ * (glf_gemm_params.colmax).  With it y is NOT written as fp32 but once, directly, as the packed pre-split image of
+ * glf_split_f16_packed -- the form the next convolution reads in its forward AND its weight gradient (a_presplit /
+ * b_presplit) -- scaled with the bound  max_c |gamma_c| invstd_c (max|x_c| + |mean_c|) + |beta_c|  >=  max |y|, which is
+ * known before a single element of y is; *amax_out receives that bound (plain store).  Needs amax_out, no residual, y != x.
+ * The fp32 y is then never materialised: the activation inside a bottleneck costs 4 B / element once instead of
+ * 4 B (write) + 4 B (re-read by the split pass) + 4 B (the image). */
 int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int ldr, float* y, int ldy, const double* sums,
                            int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
                            float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                           int relu, float* amax_out, uint8_t* relu_mask, glf_stream_t s);
+                           int relu, float* amax_out, uint8_t* relu_mask, const float* colmax, glf_stream_t s);
 /* Backward.  y is the forward output (ReLU mask = y > 0); it may be NULL when relu == 0, and also when
  * relu != 0 and there was NO residual: the mask is then recomputed from x with beta (one tensor read less
  * in both passes; with a residual the sign of y depends on it, so y is required).

@@ -611,6 +611,104 @@ def test_conv_bn_backward_with_packed_gradient_matches_fp32_gradient_path(cfg):
         _ops.set_precision("f32")
 
 
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shape,k", [((3, 9, 11, 64), 64), ((2, 7, 5, 512), 256), ((1, 33, 17, 128), 1152)])
+def test_bn_forward_writes_packed_activation(relu, shape, k):
+    """glf_gemm_nt(colmax) + glf_bn_apply_from_sums(colmax): the contraction's epilogue leaves the per-channel maxima of |x|
+    next to the batch sums, and the BatchNorm apply writes y directly as the packed pre-split fp16 image, scaled by a bound of
+    max|y| known before y exists.  Checks: colmax is exactly the column maxima of the stored C; the bound is a bound and is
+    tight (< 4x); the image reconstructs the fp32 y to 2^-21 of the bound; mean / invstd / running statistics are those of the
+    fp32-output call."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd._lib import lib, check
+    _ops.set_precision("f16x3")
+    try:
+        c = shape[-1]
+        rows = int(np.prod(shape[:-1]))
+        a = (rnd(rows, k, seed=61) + 0.1).to(DEV)
+        b = (rnd(c, k, seed=62) / np.sqrt(k)).to(DEV)
+        x = torch.empty(rows, c, device=DEV)
+        sums = _ops.stats_slot(c, DEV)
+        colmax = _ops.colmax_slot(c, DEV)
+        _ops.gemm("nt", a, b, x, M=rows, N=c, K=k, lda=k, ldb=k, ldc=c, colstats=sums, colmax=colmax)
+        torch.cuda.synchronize()
+        assert torch.equal(colmax, x.abs().amax(dim=0)), "colmax is not the column maxima of the stored C"
+        gamma, beta = rnd(c, seed=63, lo=0.5, hi=1.5).to(DEV), rnd(c, seed=64).to(DEV)
+        p = lambda t: None if t is None else t.data_ptr()
+        outs = []
+        for packed in (False, True):
+            y = torch.empty_like(x)
+            mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+            rm, rv, nbt = torch.zeros(c, device=DEV), torch.ones(c, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+            am = torch.zeros(1, device=DEV)
+            check(lib.glf_bn_apply_from_sums(p(x), c, None, c, p(y), c, p(sums), rows, c, 1e-5, 0.1, p(gamma), p(beta), p(mean), p(invstd),
+                                             p(rm), p(rv), p(nbt), int(relu), p(am), None, p(colmax) if packed else None, None), "bn_apply_from_sums")
+            torch.cuda.synchronize()
+            outs.append((y, mean, invstd, rm, rv, int(nbt), float(am)))
+        (y0, m0, i0, rm0, rv0, n0, am0), (pk, m1, i1, rm1, rv1, n1, bound) = outs
+        assert torch.equal(m0, m1) and torch.equal(i0, i1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1) and n0 == n1 == 1
+        true_max = float(y0.abs().max())
+        assert abs(am0 - true_max) <= 1e-6 * true_max
+        assert true_max <= bound <= 4.0 * true_max, (true_max, bound)
+        e = int(np.floor(np.log2(bound)))
+        s = 2.0 ** (13 - e)
+        halves = pk.view(torch.float16).view(rows, c // 4, 8).double().cpu()
+        recon = ((halves[..., :4] + halves[..., 4:] * 2.0 ** -11) / s).reshape(rows, c)
+        err = float((recon - y0.double().cpu()).abs().max())
+        assert err <= 2.0 ** -21 * bound, (err, bound)
+        # refused: a residual, in place, or no amax slot with the packed output
+        assert lib.glf_bn_apply_from_sums(p(x), c, p(y0), c, p(pk), c, p(sums), rows, c, 1e-5, 0.1, p(gamma), p(beta), p(m1), p(i1),
+                                          None, None, None, int(relu), p(am), None, p(colmax), None) != 0
+        assert lib.glf_bn_apply_from_sums(p(x), c, None, c, p(x), c, p(sums), rows, c, 1e-5, 0.1, p(gamma), p(beta), p(m1), p(i1),
+                                          None, None, None, int(relu), p(am), None, p(colmax), None) != 0
+        assert lib.glf_bn_apply_from_sums(p(x), c, None, c, p(pk), c, p(sums), rows, c, 1e-5, 0.1, p(gamma), p(beta), p(m1), p(i1),
+                                          None, None, None, int(relu), None, None, p(colmax), None) != 0
+    finally:
+        _ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 256, 64, 3, 1, 1, 1), (2, 15, 15, 128, 128, 3, 2, 1, 1), (1, 32, 32, 1024, 256, 3, 1, 2, 2),
+                                 (2, 14, 14, 64, 64, 1, 1, 0, 1)])
+def test_bottleneck_inner_activation_as_packed_image_matches_fp32_activation_path(cfg):
+    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU with the activation between the convs written ONLY as the packed image conv2
+    reads (the default inside a bottleneck) against the same chain with GLF_PACKED_ACTS off (fp32 activation + split pass):
+    the output and every gradient agree to fp32-noise level (the two differ only in the power-of-two scale of one operand)."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd.models.layers import BatchNorm2d, Conv2d, conv_bn_act
+    n, h, w, cin, mid, k, stride, pad, dil = cfg
+    _ops.set_precision("f16x3")
+    try:
+        conv1, bn1 = Conv2d(cin, mid, 1, bias=False), BatchNorm2d(mid)
+        conv2, bn2 = Conv2d(mid, mid, k, stride=stride, padding=pad, dilation=dil, bias=False), BatchNorm2d(mid)
+        with torch.no_grad():
+            conv1.weight.copy_(rnd(*conv1.weight.shape, seed=101) * 0.2)
+            conv2.weight.copy_(rnd(*conv2.weight.shape, seed=102) * 0.2)
+            for i, bn in enumerate((bn1, bn2)):
+                bn.weight.copy_(rnd(mid, seed=103 + i, lo=0.5, hi=1.5)); bn.bias.copy_(rnd(mid, seed=105 + i))
+        mods = [m.to(DEV).train() for m in (conv1, bn1, conv2, bn2)]
+        params = [p for m in mods for p in m.parameters()]
+        x0 = rnd(n, h, w, cin, seed=107)
+        res, saw = [], []
+        for flag in (True, False):
+            _ops.PACKED_ACTS = flag
+            for p in params:
+                p.grad = None
+            x = x0.to(DEV).requires_grad_(True)
+            mid_act = conv_bn_act(x, conv1, bn1, relu=True, consumer=conv2)
+            saw.append(_ops.packed_only(mid_act))
+            y = conv_bn_act(mid_act, conv2, bn2, relu=True)
+            y.backward(rnd(*y.shape, seed=108).to(DEV))
+            torch.cuda.synchronize()
+            res.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params])
+        assert saw == [True, False], saw
+        for i, (a, b) in enumerate(zip(res[0], res[1])):
+            err = float((a - b).norm() / (b.norm() + 1e-30))
+            assert err <= 2e-6, (i, err)
+    finally:
+        _ops.PACKED_ACTS = True
+        _ops.set_precision("f32")
+
+
 # ------------------------------------------------------------------------------------------ f16x3 range adversaries
 def test_f16x3_outlier_and_small_view_operands():
     """The split-fp16 kernels scale each operand by ONE power of two taken from its maximum.  Adversaries: (a) a gradient
