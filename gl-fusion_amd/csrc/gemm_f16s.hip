@@ -761,6 +761,25 @@ __global__ __launch_bounds__(NT8, 2) void gemm_rows_f16s8_kernel(const GemmArgs 
                 const int rem = row0 - en * hw;
                 ey = rem / r_w; ex = rem - ey * r_w;
             }
+            if (p_accumulate && !p_rect && !p_colstats) {
+                // C += result (a dgrad landing on the shortcut's gradient): all 16 old values are requested before the first is
+                // needed -- fetched inside the store loop, each of its 4-deep batches waited out a full memory round trip
+                float4 prev[16];
+                const int rowb = tm * BM8 + wm + r0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    prev[i] = rowb + 4 * i < pMe ? *reinterpret_cast<const float4*>(C + (long long)(rowb + 4 * i) * p_ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (rowb + 4 * i < pMe) {
+                        const float4 a = *reinterpret_cast<const float4*>(tile + (r0 + 4 * i) * 64 + c4);
+                        float4 v = make_float4(p_alpha * a.x + bv[0], p_alpha * a.y + bv[1], p_alpha * a.z + bv[2], p_alpha * a.w + bv[3]);
+                        v.x += prev[i].x; v.y += prev[i].y; v.z += prev[i].z; v.w += prev[i].w;
+                        *reinterpret_cast<float4*>(C + (long long)(rowb + 4 * i) * p_ldc + col) = v;
+                        cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    }
+                }
+            } else
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
                 const int rin = r0 + 4 * i;
