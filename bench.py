@@ -108,6 +108,28 @@ def cpu_model() -> str:
     return platform.processor() or platform.machine()
 
 
+_MFMA_PEAK = [None]
+
+
+def measured_mfma_peak() -> float:
+    """TFLOP/s of back-to-back fp16 MFMAs on random register operands on THIS box (glf_probe_mfma_f16), measured once per
+    process: what the matrix cores sustain under their power limit when no byte moves."""
+    if _MFMA_PEAK[0] is None:
+        from glfusion_amd._lib import lib, check
+        blocks, iters = 1024, 60000
+        out = torch.empty(blocks * 512, dtype=torch.float32, device="cuda")
+        best = 0.0
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 12345, torch.cuda.current_stream().cuda_stream), "probe_mfma_f16")
+            e1.record()
+            e1.synchronize()
+            best = max(best, blocks * 8 * iters * 4 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        _MFMA_PEAK[0] = best
+    return _MFMA_PEAK[0]
+
+
 def cpu_baseline(frames_per_view: int = 8, steps: int = 3):
     """The oracle's forward+backward on the host cores, same shapes per frame, a bounded sample."""
     from oracle import glfusion_ref as orc
@@ -405,8 +427,12 @@ def main():
         if precision != "f32":
             # profiles/r01_mfma_peak_microbench.txt: back-to-back 16-bit MFMAs with no memory traffic reach 2.47 PF on constant
             # operands but 1.42-1.57 PF (fp16) on random ones -- on real data the matrix cores are power-limited
-            roofline["power_limited_peak_measured"] = {"value": 1500.0, "unit": "TFLOP/s", "frac": round(achieved / 1500.0, 4),
-                                                       "source": "profiles/ubench/mfma_peak.hip, random operands"}
+            plim = measured_mfma_peak()
+            roofline["power_limited_peak_measured"] = {"value": round(plim, 1), "unit": "TFLOP/s", "frac": round(achieved / plim, 4),
+                                                       "source": "glf_probe_mfma_f16 timed in this run: 1024 workgroups x 8 wavefronts of back-to-back "
+                                                                 "v_mfma_f32_32x32x16_f16 on random register operands, no memory traffic; best of 3 "
+                                                                 "launches of ~40 ms (constant operands reach ~2.47 PF: the matrix cores are power-limited "
+                                                                 "on real data)"}
         return roofline
 
     main_leg = run_leg(args.precision)

@@ -71,7 +71,7 @@ WJ_PASS_OF = {WJ_COPY: 0, WJ_ZERO: 0, WJ_AMAX: 1, WJ_TAP_MAJOR: 2, WJ_TAP_MAJOR_
 
 _SCALARS = {
     "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
-    "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None, "uint8_t": C.c_uint8,
+    "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None, "uint8_t": C.c_uint8, "uint32_t": C.c_uint32,
 }
 
 

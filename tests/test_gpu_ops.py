@@ -709,6 +709,24 @@ def test_bottleneck_inner_activation_as_packed_image_matches_fp32_activation_pat
         _ops.set_precision("f32")
 
 
+def test_mfma_probe_counts_what_it_claims():
+    """glf_probe_mfma_f16 (bench.py's in-run power-limited peak): with constant operands (seed 0: all ones) every accumulator
+    element grows by K = 16 per MFMA, so each thread stores 16 elements x 4 accumulators x 16 x iters -- the launch really
+    issued blocks x 8 x iters x 4 MFMAs.  Bad arguments are refused."""
+    from glfusion_amd._lib import lib
+    blocks, iters = 8, 10
+    out = torch.zeros(blocks * 512, device=DEV)
+    assert lib.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.full_like(out, 16.0 * 4 * 16 * iters))
+    assert lib.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 7, None) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0
+    assert lib.glf_probe_mfma_f16(None, blocks, iters, 0, None) != 0
+    assert lib.glf_probe_mfma_f16(out.data_ptr(), 0, iters, 0, None) != 0
+    assert lib.glf_probe_mfma_f16(out.data_ptr(), blocks, 0, 0, None) != 0
+
+
 # ------------------------------------------------------------------------------------------ f16x3 range adversaries
 def test_f16x3_outlier_and_small_view_operands():
     """The split-fp16 kernels scale each operand by ONE power of two taken from its maximum.  Adversaries: (a) a gradient
