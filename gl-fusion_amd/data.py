@@ -117,7 +117,7 @@ class SyntheticPatients:
 
 
 # ------------------------------------------------------------------------------------------------------------
-# host side of the loader: the Dataset contract of datasets/loader.py:190-340 without NIfTI files
+# host side of the loader: the Dataset contract of datasets/loader.py:190-340
 # ------------------------------------------------------------------------------------------------------------
 def crop_offsets(rs, size=(RESIZE, RESIZE), crop=(CROP, CROP)) -> Tuple[int, ...]:
     """Top-left corner of a RandSpatialCropd(roi_size=crop, random_size=False) window on an image of `size`, drawn from the
@@ -130,8 +130,9 @@ def crop_offsets(rs, size=(RESIZE, RESIZE), crop=(CROP, CROP)) -> Tuple[int, ...
 
 class SegPAHDataset:
     """Seg_PAHDataset (datasets/loader.py:190-340) with the file access factored out: `infos[id]` is a dict with
-    'dataset_name', 'views_images' and 'views_labels', whose per-view entries are raw volumes [H0, W0, T] (numpy / torch) or
-    zero-argument callables returning them (the reference stores NIfTI paths there and calls nibabel, loader.py:233-234).
+    'dataset_name', 'views_images' and 'views_labels', whose per-view entries are NIfTI-1 paths (what the reference stores
+    there, loader.py:233-234; read by glfusion_amd.nifti), raw volumes [H0, W0, T] (numpy / torch) or zero-argument callables
+    returning them.
     Everything else follows the reference: the train / val / test split of the id list (loader.py:210-217), 4 samples per
     patient and epoch in train mode (loader.py:289, 335-338), the labelled-frame selection `input_select` (loader.py:429-458:
     Python's `random` module, so `random.seed` reproduces the reference's picks), the transform chain and the part masks --
@@ -164,7 +165,11 @@ class SegPAHDataset:
 
     @staticmethod
     def _volume(entry):
+        import os
         import numpy as np
+        if isinstance(entry, (str, os.PathLike)):                # the reference's case: a NIfTI path (loader.py:233-234)
+            from . import nifti
+            entry = nifti.read(entry)
         v = entry() if callable(entry) else entry
         return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
 

@@ -123,3 +123,32 @@ def test_dataset_shim_and_per_epoch_validation(tmp_path):
     assert open(tmp_path / "latest.ckpt").read() == "00001\n"
     best, dices = t.validation_and_test(net_root=str(tmp_path), infos=infos, val_list=("0_0", "0_2"), test_list=("0_1",), first_scored=0)
     assert len(dices) == 2 and best in (0, 1)
+
+
+def test_dataset_reads_nifti_paths_like_the_reference(tmp_path):
+    """The reference's infos hold NIfTI paths (loader.py:233-234 loads them with nibabel).  The same patients written to
+    .nii.gz (uint8 images, uint8 label maps, W x H x T) and handed over as paths give bit-identical items to the in-memory
+    volumes, in train (random frame + random crop) and eval (clip) mode."""
+    import random
+    import numpy as np
+    from glfusion_amd import data, nifti
+    infos = data.synthetic_infos(["4"], 3, clip_length=6, device="cpu", seed=4)
+    on_disk = {}
+    for pid, e in infos.items():
+        ent = {"dataset_name": e["dataset_name"], "fold": e["fold"], "views_images": {}, "views_labels": {}}
+        for v in e["views_images"]:
+            img, lab = e["views_images"][v](), e["views_labels"][v]()
+            img, lab = np.asarray(img.cpu()), np.asarray(lab.cpu())
+            assert float(np.abs(img - np.round(img)).max()) == 0.0 and img.min() >= 0 and img.max() <= 255     # 8-bit echo frames
+            pi, pl = tmp_path / f"{pid}_{v}_img.nii.gz", tmp_path / f"{pid}_{v}_lab.nii.gz"
+            nifti.write(pi, img.astype(np.uint8)); nifti.write(pl, lab.astype(np.uint8))
+            ent["views_images"][v], ent["views_labels"][v] = str(pi), pl                                   # str and PathLike
+        on_disk[pid] = ent
+    for kw in (dict(is_train=True, single_frame=True, crop_seed=7), dict(is_train=False, single_frame=False, clip_length=5)):
+        outs = []
+        for src in (infos, on_disk):
+            random.seed(11)
+            ds = data.SegPAHDataset(src, data_list=list(src), view_num=["4"], device=DEV, **kw)
+            outs.append([ds[i] for i in range(len(ds))])
+        for a, b in zip(*outs):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
