@@ -193,7 +193,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the secondary exact-fp32 measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the fp16-arithmetic leg (BASELINE.json configs[2])")
-    ap.add_argument("--no-graph", action="store_true", help="time the eagerly issued step instead of its hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="time the hipGraph replay of the step (engine.StepGraph) instead of the eagerly issued step")
+    ap.add_argument("--no-graph", action="store_true", help="(default since the eager step became the faster one) time the eagerly issued step")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the short measurement of the launch mode that was not timed")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -227,11 +229,13 @@ def main():
     from glfusion_amd import ops
     from glfusion_amd.ddp import GradAllReducer
     from glfusion_amd.engine import StepGraph
-    # One GPU: the timed step is a hipGraph replay.  Several ranks: the eagerly issued step by default -- its reducer launches every
-    # bucket's all-reduce while backward is still running (the overlap the design counts on), and a graph capture next to RCCL's
-    # watchdog thread is a combination no test here can exercise (one-GPU boxes); GLF_BENCH_GRAPH=1 replays the graph on every rank
-    # with the collectives launched after each replay (GradAllReducer.deferred; rehearsed over gloo in tests/test_gpu_ddp.py).
-    use_graph = not args.no_graph and os.environ.get("GLF_BENCH_GRAPH", "1" if world == 1 else "0") != "0"
+    # The timed step is the eagerly issued one.  Measured on one box, alternating (profiles/r03_graph_vs_eager.txt): eager 248.0 /
+    # 247.0 ms, hipGraph replay of the same kernels 250.5 / 251.0 ms -- the host needs ~65 ms to issue a 248 ms step, so it is not the
+    # limit, and a replay pays the runtime's node-to-node dependency handling on ~2 450 kernels.  --graph (or GLF_BENCH_GRAPH=1) times
+    # the replay: the mode for a slow or contended host (8 ms of host time per step).  Several ranks: eager as well -- its reducer
+    # launches every bucket's all-reduce while backward is still running; with --graph the collectives are launched after each
+    # replay (GradAllReducer.deferred; rehearsed over gloo in tests/test_gpu_ddp.py).
+    use_graph = (args.graph or os.environ.get("GLF_BENCH_GRAPH", "0") != "0") and not args.no_graph
 
     n_frames = args.clips * T
     model = build_model(dev)
@@ -293,9 +297,9 @@ def main():
                 print(f"[bench] {precision} step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms, reserved "
                       f"{torch.cuda.memory_reserved() / 2 ** 30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GB, "
                       f"retention off: {dict(ops._retain_off)}", file=sys.stderr, flush=True)
-        # The timed step: by default ONE hipGraph launch per step (engine.StepGraph: advance the dropout counter, rebuild the
-        # weight-derived images, forward, loss, backward -- every kernel of the eager step, recorded once); --no-graph times
-        # the eager step, whose ~3 200 Python-issued launches make the host the bottleneck.
+        # The timed step: the eager step by default; with --graph ONE hipGraph launch per step (engine.StepGraph: advance the
+        # dropout counter, rebuild the weight-derived images, forward, loss, backward -- every kernel of the eager step, recorded
+        # once).
         sg = None
         if use_graph:
             sg = StepGraph(step_core, params, warmup=2, reducer=reducer if world > 1 else None)
@@ -324,7 +328,7 @@ def main():
         loss_val = float(loss)
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
-        eager_ms = None
+        other_ms = None
         allreduce_ms = round(reducer.last_allreduce_ms(), 3) if (world > 1 and sg is not None and reducer.last_allreduce_ms() is not None) else None
         if sg is not None:
             sg.release()
@@ -333,14 +337,25 @@ def main():
                 p.grad = None
             gc.collect()
             torch.cuda.empty_cache()
-            # the same step issued eagerly from Python, for comparison (outside the metric): 1 untimed + 3 timed steps
-            step()
+        if world == 1 and precision == args.precision and not args.no_other_mode:
+            # the launch mode that was NOT timed, for comparison (outside the metric): 2 untimed + 4 timed steps, collector off
+            other = step if use_graph else StepGraph(step_core, params, warmup=2)
+            orun = other if use_graph else other.replay
+            gc.disable()
+            orun(); orun()
             fence()
             te = time.perf_counter()
-            for _ in range(3):
-                step()
+            for _ in range(4):
+                orun()
             fence()
-            eager_ms = (time.perf_counter() - te) / 3 * 1e3
+            other_ms = (time.perf_counter() - te) / 4 * 1e3
+            gc.enable()
+            if not use_graph:
+                other.release()
+                for p in params:
+                    p.grad = None
+                gc.collect()
+                torch.cuda.empty_cache()
         if os.environ.get("GLF_BENCH_CPROFILE"):          # diagnostic: where the HOST time of a step goes (outside the timed region)
             import cProfile, pstats
             pr = cProfile.Profile()
@@ -366,7 +381,7 @@ def main():
         fence()
         ops.PROFILER = None
         ops.STREAMS = streams
-        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "eager_ms": eager_ms, "host_first": host_first, "allreduce_ms": allreduce_ms}
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "other_ms": other_ms, "host_first": host_first, "allreduce_ms": allreduce_ms}
 
     def roofline_of(leg):
         precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
@@ -483,8 +498,9 @@ def main():
             "host_enqueue_ms_per_step": round(main_leg["host"] / args.steps * 1e3, 2),
             "host_enqueue_ms_first_step_idle_queue": round(main_leg["host_first"] * 1e3, 2),
             "launch": ("one hipGraph replay per step (forward + loss + backward + weight-image refresh recorded once; every kernel "
-                       "runs on every replay)" if use_graph else "eager: every kernel launched from Python"),
-            "eager_ms_per_step": (round(main_leg["eager_ms"], 2) if main_leg["eager_ms"] is not None else None),
+                       "runs on every replay)" if use_graph else "eager: every kernel launched from Python (incl. the weight-image refresh)"),
+            ("eager_ms_per_step" if use_graph else "graph_replay_ms_per_step"):
+                (round(main_leg["other_ms"], 2) if main_leg["other_ms"] is not None else None),
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16": "f16 operands (amax-scaled, one MFMA per product), fp32 accumulate, fp32 storage: NOT fp32-equivalent "

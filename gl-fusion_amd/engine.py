@@ -74,6 +74,8 @@ class StepGraph:
             reducer.deferred = True
         prev_distinct, ops.SECTIONS_DISTINCT = ops.SECTIONS_DISTINCT, True
         self._prev_distinct = prev_distinct
+        # a conv's weight gradient on a side stream is a fork nested inside a section: not capturable on ROCm 7.2 (see above)
+        prev_wgrad, ops.WGRAD_STREAM = ops.WGRAD_STREAM, False
 
         self.wtable = None                         # frozen job table of THIS model's weight images (made after the warm-up)
 
@@ -105,6 +107,7 @@ class StepGraph:
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.out = body()
         torch.cuda.current_stream(dev).wait_stream(self.stream)
+        ops.WGRAD_STREAM = prev_wgrad
         self.grads = {p: p.grad for p in self.params if p.grad is not None}      # static tensors the replays write
 
     def replay(self):
