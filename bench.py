@@ -264,6 +264,7 @@ def main():
         """The eager step.  It pays the per-update weight work a real training step pays after every optimizer step: the
         parameters are marked changed (every cache keyed on their version counter goes stale) and all weight-derived images
         (tap-major / transposed layouts, maxima, pre-split fp16 images) are rebuilt by the multi-tensor refresh."""
+        ops.advance_step(dev)                      # the device step counter (one 1-thread launch), as in the recorded step
         torch.autograd.graph.increment_version(params)
         ops.refresh_weights()
         for p in params:

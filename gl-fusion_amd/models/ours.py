@@ -171,7 +171,7 @@ class Global_and_Local(_PerViewNetworks):
             # The global fusion block needs only the encoders' outputs: it runs NEXT TO the views' head + gate sections (four
             # independent chains) instead of after them next to the local block.  The fusion blocks are the part of the step
             # with the least to overlap with -- two chains of large contractions whose streaming kernels (stack / split /
-            # statistics / LayerNorm tail) ran with nothing but their twin beside them (profiles/r03_timeline_graph_replay.txt).
+            # statistics / LayerNorm tail) ran with nothing but their twin beside them (profiles/r03_timeline_step.txt).
             k = 5 if self._third_output_is_f4 else 4
             enc = ops.parallel_sections([lambda v=v: ops.fan_out(self._encode_view(v, x[v]), k) for v in views])
 

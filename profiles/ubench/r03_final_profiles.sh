@@ -9,7 +9,8 @@ GLF_BENCH_DUMP=$R/gpurun_out/per_shape timeout -k 10 400 python bench.py --steps
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/ks1 -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-config3 --no-cpu-baseline --no-exact-f32 --no-other-mode > /tmp/ks1.log 2>&1 || { tail -3 /tmp/ks1.log; exit 1; }
 cp $(find /tmp/ks1 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ks_graph_streams.csv
-python3 $R/profiles/ubench/timeline.py $(find /tmp/ks1 -name "*kernel_trace.csv" | head -1) 4 | tee $R/gpurun_out/timeline_graph.txt
+# steps 2 .. 5 of the command's 2 warm-up + 5 timed steps: four steps inside the timed region (the trace goes on with bench.py's one-stream steps)
+python3 $R/profiles/ubench/timeline.py $(find /tmp/ks1 -name "*kernel_trace.csv" | head -1) 4 2 | tee $R/gpurun_out/timeline_graph.txt
 GLF_STREAMS=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/ks0 -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-config3 --no-cpu-baseline --no-exact-f32 --no-other-mode > /tmp/ks0.log 2>&1 || { tail -3 /tmp/ks0.log; exit 1; }
 cp $(find /tmp/ks0 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ks_one_stream.csv
 python3 $R/profiles/ubench/kstats_groups.py $R/gpurun_out/ks_one_stream.csv 11 | tee $R/gpurun_out/ks_one_stream_groups.txt

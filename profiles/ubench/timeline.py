@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""What the GPU is doing over one replayed step, from a rocprofv3 --kernel-trace CSV: for the LAST `nsteps` steps of the trace
-(delimited by counter_add_kernel launches, the first kernel of every captured step) -- wall time per step, time with at least
+"""What the GPU is doing over one step, from a rocprofv3 --kernel-trace CSV: for the LAST `nsteps` steps of the trace
+(delimited by counter_add_kernel launches, the first kernel of every step, eager or replayed) -- wall time per step, time with at least
 one contraction kernel resident, time with only streaming kernels resident, idle time, and the mean number of concurrent
-kernels.  Usage: timeline.py kernel_trace.csv [nsteps]"""
+kernels.  Usage: timeline.py kernel_trace.csv [nsteps [index of the first step]]"""
 import csv
 import re
 import sys
@@ -15,7 +15,10 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 marks = [s for s, e, n in rows if "counter_add_kernel" in n]
 if len(marks) < nsteps + 1:
     print("not enough step markers:", len(marks)); sys.exit(1)
-lo, hi = marks[-nsteps - 1], marks[-1]
+first = int(sys.argv[3]) if len(sys.argv) > 3 else len(marks) - nsteps - 1       # index of the first step's marker (default: the last nsteps)
+if first + nsteps >= len(marks):
+    print("not enough step markers after", first, ":", len(marks)); sys.exit(1)
+lo, hi = marks[first], marks[first + nsteps]
 sel = [(s, e, n) for s, e, n in rows if s >= lo and s < hi]
 is_gemm = lambda n: bool(re.search(r"gemm_rows|gemm_tn_|attn_", n))
 ev = []
