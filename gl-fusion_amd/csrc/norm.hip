@@ -50,8 +50,13 @@ struct OpBnBwd {          // (dy', dy' * xhat), dy' = dy * (y > 0) when relu; y 
     const float* dy; int lddy; const float* x; int ldx; const float* y; int ldy;
     const float* mean; const float* invstd; const float* gamma; const float* beta; int relu;
     const unsigned char* mask; int c4;          // relu with a residual: the forward's sign bits, one byte per float4 (instead of y)
+    const float* dy2; int lddy2;                // second addend of the incoming gradient (a fan-in not yet summed), or null
     __device__ void operator()(int r, int c, float4& a, float4& b) const {
         a = *reinterpret_cast<const float4*>(dy + (long long)r * lddy + c);
+        if (dy2) {
+            const float4 a2 = *reinterpret_cast<const float4*>(dy2 + (long long)r * lddy2 + c);
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+        }
         const float4 xx = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -449,7 +454,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx,
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
                                                            long long total4, int c4, int relu, int training, float inv_n,
-                                                           float* __restrict__ amax_out, int packed, const unsigned char* __restrict__ mask) {
+                                                           float* __restrict__ amax_out, int packed, const unsigned char* __restrict__ mask,
+                                                           const float* __restrict__ dy2, int lddy2) {
     // packed != 0: dx is written as the packed pre-split fp16 image (glf_split_f16_packed's format) scaled by *amax_out, which
     // then holds an upper bound of max |dx| computed by bnbwd_finalize (not a by-product of this kernel)
     float am = 0.f, sc = 1.f, sc_inv = 1.f;
@@ -458,6 +464,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
         float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        if (dy2) {
+            const float4 g2 = *reinterpret_cast<const float4*>(dy2 + r * lddy2 + c);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+        }
         const float4 is = *reinterpret_cast<const float4*>(k.invstd + c);
         const float4 ga = *reinterpret_cast<const float4*>(k.gamma + c);
         float4 xx = make_float4(0.f, 0.f, 0.f, 0.f), mu = xx;
@@ -712,7 +722,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                           int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
-                          const uint8_t* relu_mask, glf_stream_t s) {
+                          const uint8_t* relu_mask, const float* dy2, int lddy2, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
     if (relu_mask) y = nullptr;
@@ -722,8 +732,9 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     REQ_C4(c); REQ_AL(dy, "dy"); REQ_AL(x, "x"); REQ_AL(dx, "dx"); REQ_LD(lddy, "lddy"); REQ_LD(ldx, "ldx"); REQ_LD(lddx, "lddx");
     if (relu && y) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
+    if (dy2) { REQ_AL(dy2, "dy2"); REQ_LD(lddy2, "lddy2"); }
     const int slices = n_slices_c(rows, c);
-    const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu, relu_mask, c / 4};
+    const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu, relu_mask, c / 4, dy2, lddy2};
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
     float* s_dy = dbeta ? dbeta : sums;
@@ -743,7 +754,7 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
                        Coef{mean, invstd, gamma, beta}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
-                       1.0f / (float)rows, amax_out, packed_dx, relu_mask);
+                       1.0f / (float)rows, amax_out, packed_dx, relu_mask, dy2, lddy2);
     return glf::check_launch("bn_bwd_apply");
 }
 

@@ -30,9 +30,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward_nhwc(self, x):
-        # x feeds the shortcut and conv1: its two gradients meet in ONE pass (ops.fan_out) instead of autograd's add
-        x, xs = ops.fan_out(x, 2)
+    def forward_nhwc(self, x, sole_reader: bool = False):
+        # x feeds the shortcut and conv1: its two gradients meet in ONE pass (ops.fan_out) instead of autograd's add -- or, when
+        # x is the previous block's output and nobody else reads it (sole_reader, set by Stage), in no pass of their own at all:
+        # that block's last BatchNorm backward adds them while reading
+        x, xs = ops.fan_out(x, 2, lazy=sole_reader)
         if self.downsample is None and x is not xs:
             ops.join_gradients(x, xs)     # identity shortcut: conv1's dgrad accumulates onto the shortcut's gradient
         idn = xs if self.downsample is None else conv_bn_act(xs, self.downsample[0], self.downsample[1], relu=False)
@@ -48,8 +50,8 @@ class Stage(nn.Sequential):
     """layerN: a Sequential of Bottlenecks that stays NHWC between its blocks."""
 
     def forward_nhwc(self, x):
-        for blk in self:
-            x = blk.forward_nhwc(x)
+        for i, blk in enumerate(self):
+            x = blk.forward_nhwc(x, sole_reader=i > 0)       # block i > 0 reads the output of block i - 1, which nobody else sees
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

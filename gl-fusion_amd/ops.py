@@ -1314,7 +1314,13 @@ class BatchNormActFn(Function):
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
         rows, c, relu, training, has_res, ldy = ctx.cfg
+        dy2 = getattr(dy, "_glf_addend", None)    # fan_out(lazy=True): the two gradients of a block input arrive unsummed
+        lddy2 = 0
         dy, lddy = _rows_view(dy)                 # may be a column slice of the concat-free projection's gradient
+        if dy2 is not None:
+            if dy2.shape != dy.shape:
+                raise RuntimeError("glfusion_amd: the two addends of a lazy fan-in gradient differ in shape")
+            dy2, lddy2 = _rows_view(dy2)
         dev = dy.device
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
@@ -1328,7 +1334,7 @@ class BatchNormActFn(Function):
         mask = y if ctx.has_mask else None
         check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, None if ctx.has_mask else _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta),
                              _p(dx), c, _p(dres), c, _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am),
-                             int(packed), _p(mask), _stream()), "bn_bwd")
+                             int(packed), _p(mask), _p(dy2), lddy2, _stream()), "bn_bwd")
         set_amax(dx, am)
         if packed:
             dx._glf_packed_only = True
@@ -1550,8 +1556,9 @@ class FanOutFn(Function):
     autograd's pairwise accumulation (3 (k-1) tensor passes through torch's add kernel)."""
 
     @staticmethod
-    def forward(ctx, x, k: int):
+    def forward(ctx, x, k: int, lazy: bool = False):
         ctx.k = k
+        ctx.lazy = bool(lazy) and k == 2 and LAZY_FAN_IN
         outs = tuple(x.view_as(x) for _ in range(k))
         am = amax_of(x)                       # one measurement (or the producer's by-product) serves every alias
         share = [None]                        # ... and so does one pre-split image, whichever consumer makes it first
@@ -1565,23 +1572,35 @@ class FanOutFn(Function):
     def backward(ctx, *dys):
         live = [_contig(d) for d in dys if d is not None]
         if not live:
-            return None, None
+            return None, None, None
         if len(live) == 1:
-            return live[0], None
+            return live[0], None, None
+        if ctx.lazy and live[0].shape == live[1].shape and not packed_only(live[0]) and not packed_only(live[1]):
+            # the producer of x is a BatchNorm(+residual) whose backward adds the two while reading them (glf_bn_bwd dy2): the
+            # caller of fan_out(lazy=True) guarantees that node is the ONLY reader of this gradient
+            a = live[0]
+            a._glf_addend = live[1]
+            return a, None, None
         out = torch.empty_like(live[0])
         n = out.numel()
         if n % 4 != 0 or any(d.shape != out.shape for d in live) or len(live) > 8:
             raise RuntimeError("fan_out: gradients must share one shape with numel % 4 == 0 (<= 8 branches)")
         arr = (C.c_void_p * len(live))(*[d.data_ptr() for d in live])
         check(lib.glf_add_n(arr, len(live), _p(out), n, _stream()), "add_n")
-        return out, None
+        return out, None, None
 
 
-def fan_out(x: torch.Tensor, k: int):
-    """k aliases of x for k consumers (use each exactly once)."""
+# The two gradients of a residual block's input go to the previous block's last BatchNorm unsummed (glf_bn_bwd adds them while reading)
+LAZY_FAN_IN = os.environ.get("GLF_LAZY_FAN_IN", "1") != "0"
+
+
+def fan_out(x: torch.Tensor, k: int, lazy: bool = False):
+    """k aliases of x for k consumers (use each exactly once).  lazy (k == 2): the caller guarantees that x is the output of a
+    batch_norm_act call and that this fan_out is its ONLY reader -- the backward then hands the two incoming gradients to that
+    BatchNorm's backward as a pair (first + `_glf_addend`) instead of summing them in a pass of its own."""
     if k <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
         return tuple(x for _ in range(max(k, 1)))
-    return FanOutFn.apply(x, k)
+    return FanOutFn.apply(x, k, lazy)
 
 
 class GradJoin:

@@ -358,12 +358,16 @@ int glf_bn_apply_from_sums(const float* x, int ldx, const float* residual, int l
  * gradient of a conv output exists once, in the form its consumers want, and the separate split pass (one read + one write
  * of the tensor) is gone.  The image's power-of-two scale must be known before the first element is written: the reduction
  * pass also takes max|dy'| and max|xhat| per channel, and *amax_out (required, zeroed by the caller) receives the upper
- * bound of max|dx| derived from them (typically within 2x of the true maximum); pass the same scalar as amax_a. */
+ * bound of max|dx| derived from them (typically within 2x of the true maximum); pass the same scalar as amax_a.
+ * dy2 (may be NULL; row stride lddy2): a second addend of the incoming gradient -- the node sees dy + dy2.  The input of a
+ * residual block feeds its shortcut and its first conv (models/resnet.py:59-79), so the gradient that reaches the previous
+ * block's last BatchNorm is a sum of two tensors: both passes add them while reading instead of a separate add kernel
+ * writing the sum (3 tensor passes) that both passes then read (2 more). */
 int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
                const float* mean, const float* invstd, const float* gamma, const float* beta /* may be NULL with y */,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
-               const uint8_t* relu_mask /* glf_bn_apply's sign bytes: replaces y */, glf_stream_t s);
+               const uint8_t* relu_mask /* glf_bn_apply's sign bytes: replaces y */, const float* dy2, int lddy2, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise pieces of the path.

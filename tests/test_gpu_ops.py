@@ -548,7 +548,7 @@ def test_bn_backward_writes_packed_gradient(relu, res, training, shape):
             ws = torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=DEV)
             p = lambda t: None if t is None else t.data_ptr()
             check(lib.glf_bn_bwd(p(dy), c, p(x), c, p(y) if (relu and res) else None, c, p(mean), p(invstd), p(gamma), p(beta), p(dx), c,
-                                 p(dres), c, p(dg), p(db), rows, c, int(relu), int(training), p(ws), p(am), packed, None, None), "bn_bwd")
+                                 p(dres), c, p(dg), p(db), rows, c, int(relu), int(training), p(ws), p(am), packed, None, None, 0, None), "bn_bwd")
             torch.cuda.synchronize()
             outs.append((dx, dres, dg, db, float(am)))
         (dx0, dres0, dg0, db0, am0), (pk, dres1, dg1, db1, bound) = outs
@@ -567,6 +567,82 @@ def test_bn_backward_writes_packed_gradient(relu, res, training, shape):
         assert err <= 2.0 ** -21 * bound, (err, bound)
     finally:
         _ops.set_precision("f32")
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("shape", [(3, 9, 11, 64), (2, 7, 5, 2048)])
+def test_bn_backward_adds_two_gradient_addends_while_reading(packed, shape):
+    """glf_bn_bwd(dy2): the node sees dy + dy2 without the sum being materialised.  Against the same call on the pre-added
+    tensor: dx (fp32 or packed image), dres, dgamma, dbeta and the bound are bit-identical (the kernels add in the same order)."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd._lib import lib, check
+    _ops.set_precision("f16x3")
+    try:
+        c = shape[-1]
+        rows = int(np.prod(shape[:-1]))
+        x = (rnd(*shape, seed=181) * 2 + 0.4).to(DEV)
+        a, b = (rnd(*shape, seed=182) * 3.0).to(DEV), (rnd(*shape, seed=186) * 0.7).to(DEV)
+        gamma, beta = rnd(c, seed=183, lo=0.5, hi=1.5).to(DEV), rnd(c, seed=184).to(DEV)
+        mean, invstd = x.view(rows, c).mean(0).contiguous(), (1.0 / (x.view(rows, c).var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+        r = rnd(*shape, seed=185).to(DEV)
+        y = torch.relu((x - mean) * invstd * gamma + beta + r).contiguous()
+        p = lambda t: None if t is None else t.data_ptr()
+        outs = []
+        for dy, dy2 in (((a + b).contiguous(), None), (a, b)):
+            dx, dres = torch.empty_like(x), torch.empty_like(x)
+            dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+            am = torch.zeros(1, device=DEV)
+            ws = torch.empty(int(lib.glf_bn_workspace(rows, c)), dtype=torch.float64, device=DEV)
+            check(lib.glf_bn_bwd(p(dy), c, p(x), c, p(y), c, p(mean), p(invstd), p(gamma), p(beta), p(dx), c, p(dres), c, p(dg), p(db),
+                                 rows, c, 1, 1, p(ws), p(am), packed, None, p(dy2), c, None), "bn_bwd")
+            torch.cuda.synchronize()
+            outs.append((dx, dres, dg, db, am))
+        for u, v in zip(*outs):
+            assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+        assert lib.glf_bn_bwd(p(a), c, p(x), c, p(y), c, p(mean), p(invstd), p(gamma), p(beta), p(dx), c, p(dres), c, p(dg), p(db),
+                              rows, c, 1, 1, p(ws), p(am), packed, None, p(b), c + 2, None) != 0
+    finally:
+        _ops.set_precision("f32")
+
+
+def test_stage_hands_block_input_gradients_to_batchnorm_unsummed():
+    """models.resnet.Stage: blocks after the first read the previous block's output through fan_out(lazy=True); their two
+    gradients reach that block's last BatchNorm as a pair.  Same stage with GLF_LAZY_FAN_IN off (one add_n pass per block):
+    input gradient and every parameter gradient agree bit for bit in exact fp32, and the lazy path really ran."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd.models.resnet import ResNet
+    torch.manual_seed(0)
+    net = ResNet(layers=(3, 1, 1, 1))
+    stage = net.layer1.to(DEV).train()
+    with torch.no_grad():
+        for i, prm in enumerate(stage.parameters()):
+            prm.copy_(rnd(*prm.shape, seed=300 + i) * (0.2 if prm.dim() > 1 else 1.0) + (1.0 if prm.dim() == 1 and i % 2 == 0 else 0.0))
+    x0 = rnd(2, 14, 14, 64, seed=299)
+    res, seen = [], []
+    orig = _ops.FanOutFn.backward
+    for flag in (True, False):
+        _ops.LAZY_FAN_IN = flag
+        for prm in stage.parameters():
+            prm.grad = None
+        x = x0.to(DEV).requires_grad_(True)
+        y = stage.forward_nhwc(x)
+        n_add = [0]
+        real_check = _ops.check
+        def counting(rc, what, _n=n_add, _c=real_check):
+            _n[0] += what == "add_n"
+            return _c(rc, what)
+        _ops.check = counting
+        try:
+            y.backward(rnd(*y.shape, seed=298).to(DEV))
+        finally:
+            _ops.check = real_check
+        torch.cuda.synchronize()
+        seen.append(n_add[0])
+        res.append([x.grad.clone()] + [prm.grad.clone() for prm in stage.parameters()])
+    _ops.LAZY_FAN_IN = True
+    assert seen == [1, 3], seen            # lazy: only the first block (whose input is not a block output) still sums in a pass
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 1, 1, 1), (2, 14, 14, 128, 256, 1, 1, 0, 1), (1, 28, 28, 256, 256, 3, 1, 12, 12),
