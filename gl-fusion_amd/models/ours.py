@@ -102,9 +102,9 @@ class _PerViewNetworks(nn.Module):
         f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
         f = blk[3].forward_nhwc(f)
         f = self.layer1[view].forward_nhwc(f)
-        f = self.layer2[view].forward_nhwc(f)
-        f = self.layer3[view].forward_nhwc(f)
-        return self.layer4[view].forward_nhwc(f)
+        f = self.layer2[view].forward_nhwc(f, sole_reader=True)        # each stage output has one reader: the next stage
+        f = self.layer3[view].forward_nhwc(f, sole_reader=True)
+        return self.layer4[view].forward_nhwc(f, sole_reader=True)
 
     def _encode(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         views = list(self.view_num)
@@ -475,7 +475,7 @@ class Global_and_Local_CPS(nn.Module):
         f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
         f = blk[3].forward_nhwc(f)
         for l in ("layer1", "layer2", "layer3", "layer4"):
-            f = g(l).forward_nhwc(f)
+            f = g(l).forward_nhwc(f, sole_reader=l != "layer1")         # a stage output has one reader: the next stage
         return f
 
     def _net(self, x, sfx: str, shared_encoder: bool):

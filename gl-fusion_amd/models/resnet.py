@@ -49,9 +49,11 @@ class Bottleneck(nn.Module):
 class Stage(nn.Sequential):
     """layerN: a Sequential of Bottlenecks that stays NHWC between its blocks."""
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, sole_reader: bool = False):
+        """sole_reader: x is the output of the previous stage's last block (a BatchNorm + residual + ReLU) and this stage is its
+        only reader -- never true for layer1, whose input comes out of the max-pool."""
         for i, blk in enumerate(self):
-            x = blk.forward_nhwc(x, sole_reader=i > 0)       # block i > 0 reads the output of block i - 1, which nobody else sees
+            x = blk.forward_nhwc(x, sole_reader=sole_reader or i > 0)       # block i > 0 reads block i - 1's output, which nobody else sees
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
