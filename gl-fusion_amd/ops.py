@@ -1558,7 +1558,8 @@ class FanOutFn(Function):
     @staticmethod
     def forward(ctx, x, k: int, lazy: bool = False):
         ctx.k = k
-        ctx.lazy = bool(lazy) and k == 2 and LAZY_FAN_IN
+        # lazy only when x really is a batch_norm_act output: its backward is the one node that understands `_glf_addend`
+        ctx.lazy = bool(lazy) and k == 2 and LAZY_FAN_IN and type(x.grad_fn).__name__ == "BatchNormActFnBackward"
         outs = tuple(x.view_as(x) for _ in range(k))
         am = amax_of(x)                       # one measurement (or the producer's by-product) serves every alias
         share = [None]                        # ... and so does one pre-split image, whichever consumer makes it first
