@@ -564,6 +564,110 @@ extern "C" int glf_stem7x7_fwd(const float* x, const float* w, const float* bias
     hipLaunchKernelGGL((stem_fwd_kernel<STEM_CO>), grid, dim3(256), 0, glf::S(s), x, w, bias, y, h, wdt, ho, wo, pad);
     return glf::check_launch("stem7x7_fwd");
 }
+// Inference-mode stem in ONE kernel: conv7x7 (Cin = 1) + bias -> BatchNorm (given mean / invstd: the running statistics) -> ReLU ->
+// max-pool 3x3 stride 2 pad 1.  One workgroup = a 16 x 16 tile of conv outputs starting one row / column before an even
+// coordinate = the 3x3 windows of 7 x 7 pooled outputs (15 of its 16 rows / columns are used).  The conv tile is evaluated like
+// stem_fwd_kernel's (same patch, same tap order: bit-identical values), 16 channels at a time, normalised, parked in LDS and
+// pooled from there: the [N][Ho][Wo][64] conv output and its normalised copy never reach memory (2 x 3 MB per 112 x 112 frame).
+constexpr int SPOOL = 7;                   // pooled outputs per tile edge
+__global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ y, int h, int wd, int ho, int wo, int hp, int wp, int pad,
+                                                                 float* __restrict__ amax_out) {
+    __shared__ float patch[SP * SP];
+    __shared__ __attribute__((aligned(16))) float wt[49 * STEM_CO];       // [tap][co]
+    __shared__ __attribute__((aligned(16))) float coef[5 * STEM_CO];      // bias, mean, invstd, gamma, beta
+    constexpr int TP = ST * ST + 1;                                       // pixel stride of a channel row (odd: no bank conflicts)
+    __shared__ float tile[16 * TP];                                       // [16 channels][conv pixel], normalised + ReLU
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, py0 = blockIdx.y * SPOOL, px0 = blockIdx.x * SPOOL;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;                       // first conv row / column of the tile (may be -1)
+    for (int i = tid; i < 49 * STEM_CO; i += 256) { const int co = i / 49, t = i - co * 49; wt[t * STEM_CO + co] = w[i]; }
+    for (int i = tid; i < STEM_CO; i += 256) {
+        coef[i] = bias ? bias[i] : 0.f; coef[STEM_CO + i] = mean[i]; coef[2 * STEM_CO + i] = invstd[i];
+        coef[3 * STEM_CO + i] = gamma[i]; coef[4 * STEM_CO + i] = beta[i];
+    }
+    for (int i = tid; i < SP * SP; i += 256) {
+        const int qy = i / SP, qx = i - qy * SP;
+        const int iy = oy0 - pad + qy, ix = ox0 - pad + qx;
+        patch[i] = (iy >= 0 && iy < h && ix >= 0 && ix < wd) ? x[((long long)n * h + iy) * wd + ix] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float xin[49];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) xin[ky * 7 + kx] = patch[(ty + ky) * SP + tx + kx];
+    // pooling role of this thread: pooled pixel (tid >> 2) of the 7 x 7 (threads 0 .. 195), channels 4 (tid & 3) .. of the group
+    const int pp = tid >> 2, pc = (tid & 3) * 4;
+    const int ppy = pp / SPOOL, ppx = pp - ppy * SPOOL;
+    const bool pool_ok = pp < SPOOL * SPOOL && py0 + ppy < hp && px0 + ppx < wp;
+    float am = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < STEM_CO; c0 += 16) {
+        float4 a0 = *reinterpret_cast<const float4*>(coef + c0), a1 = *reinterpret_cast<const float4*>(coef + c0 + 4);
+        float4 a2 = *reinterpret_cast<const float4*>(coef + c0 + 8), a3 = *reinterpret_cast<const float4*>(coef + c0 + 12);
+#pragma unroll
+        for (int t = 0; t < 49; ++t) {
+            const float v = xin[t];
+            const float4 w0 = *reinterpret_cast<const float4*>(wt + t * STEM_CO + c0);
+            const float4 w1 = *reinterpret_cast<const float4*>(wt + t * STEM_CO + c0 + 4);
+            const float4 w2 = *reinterpret_cast<const float4*>(wt + t * STEM_CO + c0 + 8);
+            const float4 w3 = *reinterpret_cast<const float4*>(wt + t * STEM_CO + c0 + 12);
+            a0.x = fmaf(v, w0.x, a0.x); a0.y = fmaf(v, w0.y, a0.y); a0.z = fmaf(v, w0.z, a0.z); a0.w = fmaf(v, w0.w, a0.w);
+            a1.x = fmaf(v, w1.x, a1.x); a1.y = fmaf(v, w1.y, a1.y); a1.z = fmaf(v, w1.z, a1.z); a1.w = fmaf(v, w1.w, a1.w);
+            a2.x = fmaf(v, w2.x, a2.x); a2.y = fmaf(v, w2.y, a2.y); a2.z = fmaf(v, w2.z, a2.z); a2.w = fmaf(v, w2.w, a2.w);
+            a3.x = fmaf(v, w3.x, a3.x); a3.y = fmaf(v, w3.y, a3.y); a3.z = fmaf(v, w3.z, a3.z); a3.w = fmaf(v, w3.w, a3.w);
+        }
+        // (x - mean) * invstd * gamma + beta, the expression of glf_bn_apply.  Tile positions outside the conv output hold a finite
+        // value of no meaning: the pooling loop below skips them by coordinate (selecting here, per element, drove the register
+        // allocator to 1.4 KB of scratch per lane)
+        auto park = [&](const float4& a, int cb) {
+            const float4 mu = *reinterpret_cast<const float4*>(coef + STEM_CO + c0 + cb), is = *reinterpret_cast<const float4*>(coef + 2 * STEM_CO + c0 + cb);
+            const float4 ga = *reinterpret_cast<const float4*>(coef + 3 * STEM_CO + c0 + cb), be = *reinterpret_cast<const float4*>(coef + 4 * STEM_CO + c0 + cb);
+            const float v0 = (a.x - mu.x) * is.x * ga.x + be.x, v1 = (a.y - mu.y) * is.y * ga.y + be.y;
+            const float v2 = (a.z - mu.z) * is.z * ga.z + be.z, v3 = (a.w - mu.w) * is.w * ga.w + be.w;
+            tile[(cb + 0) * TP + tid] = fmaxf(v0, 0.f); tile[(cb + 1) * TP + tid] = fmaxf(v1, 0.f);
+            tile[(cb + 2) * TP + tid] = fmaxf(v2, 0.f); tile[(cb + 3) * TP + tid] = fmaxf(v3, 0.f);
+        };
+        park(a0, 0); park(a1, 4); park(a2, 8); park(a3, 12);
+        __syncthreads();
+        if (pool_ok) {
+            float m[4] = {-1.f, -1.f, -1.f, -1.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int pix = (2 * ppy + dy) * ST + 2 * ppx + dx;
+                    const int cy = oy0 + 2 * ppy + dy, cx = ox0 + 2 * ppx + dx;
+                    const bool in = cy >= 0 && cy < ho && cx >= 0 && cx < wo;       // the window hangs over the conv output at the borders
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = in ? fmaxf(m[k], tile[(pc + k) * TP + pix]) : m[k];
+                }
+            *reinterpret_cast<float4*>(y + (((long long)n * hp + py0 + ppy) * wp + px0 + ppx) * STEM_CO + c0 + pc) = make_float4(m[0], m[1], m[2], m[3]);
+            am = fmaxf(fmaxf(am, fmaxf(m[0], m[1])), fmaxf(m[2], m[3]));
+        }
+        __syncthreads();
+    }
+    if (amax_out) block_amax(am, amax_out);
+}
+
+extern "C" int glf_stem7x7_bn_relu_pool(const float* x, const float* w, const float* bias, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float* y, int n, int h, int wdt, int cout, int pad,
+                                        float* amax_out, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && w && mean && invstd && gamma && beta && y, GLF_ERR_NULL, "stem7x7_bn_relu_pool: null argument");
+    GLF_REQUIRE(cout == STEM_CO, GLF_ERR_UNSUPPORTED, "stem7x7: Cout must be 64 (got %d)", cout);
+    const int ho = h + 2 * pad - 6, wo = wdt + 2 * pad - 6;
+    GLF_REQUIRE(n > 0 && n <= 65535 && ho > 0 && wo > 0 && pad >= 0 && pad <= 3, GLF_ERR_BAD_SHAPE, "stem7x7_bn_relu_pool: bad shape");
+    const int hp = (ho - 1) / 2 + 1, wp = (wo - 1) / 2 + 1;             // MaxPool2d(3, stride 2, padding 1)
+    GLF_REQUIRE(al16(y), GLF_ERR_BAD_SHAPE, "stem7x7_bn_relu_pool: y must be 16-byte aligned");
+    dim3 grid((wp + SPOOL - 1) / SPOOL, (hp + SPOOL - 1) / SPOOL, n);
+    hipLaunchKernelGGL(stem_bn_relu_pool_kernel, grid, dim3(256), 0, glf::S(s), x, w, bias, mean, invstd, gamma, beta, y, h, wdt, ho, wo, hp, wp, pad, amax_out);
+    return glf::check_launch("stem7x7_bn_relu_pool");
+}
 extern "C" size_t glf_stem7x7_wgrad_workspace(int n, int h, int wdt, int cout, int pad) {
     const int ho = h + 2 * pad - 6, wo = wdt + 2 * pad - 6;
     if (n <= 0 || ho <= 0 || wo <= 0) return 0;

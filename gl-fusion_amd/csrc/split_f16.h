@@ -51,4 +51,19 @@ __device__ __forceinline__ void pow2_scale(const float* amax, float& s, float& i
     }
 }
 
+// (shared by norm.hip and pointwise.hip; 256-thread workgroups)
+// by-product of the applies for the f16x3 contraction kernels: max |value written|, one atomic per block
+// (*amax_out must hold a non-negative float, normally 0, before the launch)
+__device__ __forceinline__ void block_amax(float m, float* __restrict__ amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
+    }
+}
+
 }  // namespace

@@ -102,3 +102,16 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None, con
                 sums._glf_colmax = ops.colmax_slot(conv.out_channels, x.device)     # bounds the BatchNorm output before it exists
             return bn.forward_nhwc(conv.forward_nhwc(x, sums), relu=relu, residual=residual, sums=sums, packed_grad=pg, packed_out=po)
     return bn.forward_nhwc(conv.forward_nhwc(x), relu=relu, residual=residual, packed_grad=pg)
+
+
+def init_block_nhwc(x, conv: Conv2d, bn: BatchNorm2d, pool: MaxPool2d):
+    """init_block = conv1 (7x7, Cin 1), bn1, relu, maxpool (ours.py:1725-1730, 1796) on an NHWC [N,H,W,1] input.  Evaluation under
+    no_grad with running statistics: ONE launch (glf_stem7x7_bn_relu_pool; the conv output never reaches memory).  Training, or any
+    call that records a graph: conv -> BatchNorm (batch statistics) -> ReLU -> max-pool as three kernels with their backward."""
+    stride, pad, dil = conv._geom()
+    fused = (ops.FUSED_STEM and not torch.is_grad_enabled() and not (bn.training or bn.running_mean is None)
+             and conv.in_channels == 1 and conv.out_channels == 64 and conv.kernel_size == (7, 7) and stride == 1 and dil == 1 and pad <= 3
+             and (_one(pool.kernel_size), _one(pool.stride), _one(pool.padding), _one(pool.dilation)) == (3, 2, 1, 1) and not pool.ceil_mode)
+    if fused:
+        return ops.stem_bn_relu_pool(x, conv.weight, conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, float(bn.eps), pad)
+    return pool.forward_nhwc(conv_bn_act(x, conv, bn, relu=True))

@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import ops
 from ..fusion import tpavi_forward
-from .layers import Conv2d, ReLU, conv_bn_act
+from .layers import Conv2d, ReLU, conv_bn_act, init_block_nhwc
 from .segmentation import deeplabv3_resnet50_iekd
 
 
@@ -99,8 +99,7 @@ class _PerViewNetworks(nn.Module):
     # -- encoder (ours.py:1795-1800) -------------------------------------------------------
     def _encode_view(self, view: str, xv: torch.Tensor) -> torch.Tensor:
         blk = self.init_block[view]
-        f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
-        f = blk[3].forward_nhwc(f)
+        f = init_block_nhwc(ops.to_nhwc(xv), blk[0], blk[1], blk[3])
         f = self.layer1[view].forward_nhwc(f)
         f = self.layer2[view].forward_nhwc(f, sole_reader=True)        # each stage output has one reader: the next stage
         f = self.layer3[view].forward_nhwc(f, sole_reader=True)
@@ -472,8 +471,7 @@ class Global_and_Local_CPS(nn.Module):
     def _encode(self, sfx: str, view: str, xv: torch.Tensor) -> torch.Tensor:
         g = lambda name: getattr(self, name + sfx)[view]
         blk = g("init_block")
-        f = conv_bn_act(ops.to_nhwc(xv), blk[0], blk[1], relu=True)
-        f = blk[3].forward_nhwc(f)
+        f = init_block_nhwc(ops.to_nhwc(xv), blk[0], blk[1], blk[3])
         for l in ("layer1", "layer2", "layer3", "layer4"):
             f = g(l).forward_nhwc(f, sole_reader=l != "layer1")         # a stage output has one reader: the next stage
         return f

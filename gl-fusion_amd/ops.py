@@ -1198,6 +1198,29 @@ def stem7x7(x, weight, bias, pad: int):
     return StemFn.apply(x, weight, bias, pad)
 
 
+FUSED_STEM = os.environ.get("GLF_FUSED_STEM", "1") != "0"
+
+
+def stem_bn_relu_pool(x, weight, bias, running_mean, running_var, gamma, beta, eps: float, pad: int):
+    """Inference-mode init_block in one launch (glf_stem7x7_bn_relu_pool): maxpool3x3s2(relu(bn_eval(conv7x7(x) + bias))) on
+    [N,H,W,1] -> [N,Hp,Wp,64].  Forward only (no autograd node): for no_grad evaluation."""
+    _chk(x, "stem input"); _chk(weight, "stem weight")
+    x = _contig(x)
+    n, h, w, _ = x.shape
+    cout = weight.shape[0]
+    ho, wo = h + 2 * pad - 6, w + 2 * pad - 6
+    dev = x.device
+    mean = torch.empty(cout, dtype=torch.float32, device=dev)
+    invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+    check(lib.glf_bn_eval_coeffs(_p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), cout, _stream()), "bn_eval_coeffs")
+    y = torch.empty(n, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, cout, dtype=torch.float32, device=dev)
+    am = amax_slot(dev)
+    check(lib.glf_stem7x7_bn_relu_pool(_p(x), _p(_contig(weight.detach())), _p(bias), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y),
+                                       n, h, w, cout, pad, _p(am), _stream()), "stem7x7_bn_relu_pool")
+    set_amax(y, am)
+    return y
+
+
 # ----------------------------------------------------------------------------------------
 # writing a branch's last kernel straight into a column slice of a wider buffer (ASPP: no concat, ONE projection GEMM)
 # ----------------------------------------------------------------------------------------

@@ -293,6 +293,15 @@ int glf_weights_refresh(const glf_weight_job* jobs_dev, const int* pass_first, c
  * ------------------------------------------------------------------------------------- */
 int glf_stem7x7_fwd(const float* x, const float* w, const float* bias, float* y,
                     int n, int h, int wdt, int cout, int pad, glf_stream_t s);
+/* Inference-mode stem in one launch (SURVEY 8b `stem7x7_bn_relu_pool`; ours.py:1725-1730, 1796: init_block = conv1, bn1, relu,
+ * maxpool): y [N][Hp][Wp][Cout] = maxpool3x3s2p1(relu(bn(conv7x7(x) + bias))) with Hp = (Ho - 1) / 2 + 1 and the BatchNorm given by
+ * mean / invstd (glf_bn_eval_coeffs of the running statistics), gamma, beta.  The conv output and its normalised copy are never
+ * written.  Values equal the three-launch chain's bit for bit (same tap order, same BatchNorm expression).  amax_out (may be NULL):
+ * as in glf_bn_apply.  Forward only: a train-mode step needs the batch statistics of the conv output before it can normalise, and
+ * the conv output again in backward -- the three kernels stay. */
+int glf_stem7x7_bn_relu_pool(const float* x, const float* w, const float* bias, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, float* y, int n, int h, int wdt, int cout, int pad,
+                             float* amax_out, glf_stream_t s);
 /* dW [Cout][49] and db [Cout]; partial must hold glf_stem7x7_wgrad_workspace() floats. */
 size_t glf_stem7x7_wgrad_workspace(int n, int h, int wdt, int cout, int pad);
 int glf_stem7x7_wgrad(const float* x, const float* dy, float* dw, float* db, float* partial,

@@ -785,6 +785,52 @@ def test_bottleneck_inner_activation_as_packed_image_matches_fp32_activation_pat
         _ops.set_precision("f32")
 
 
+@pytest.mark.parametrize("shape", [(3, 112, 112), (2, 57, 40), (1, 9, 9), (2, 224, 224)])
+def test_fused_inference_stem_equals_the_three_kernel_chain(shape):
+    """glf_stem7x7_bn_relu_pool: conv7x7 + bias -> BatchNorm (running statistics) -> ReLU -> max-pool 3x3/2 in one launch
+    against the conv / BatchNorm / pool kernels it replaces under no_grad evaluation: bit-identical values and maximum; and against
+    torch's own ops on the CPU at 1e-5.  Odd sizes exercise ragged pooled tiles and windows that hang over the conv output."""
+    from glfusion_amd import ops as _ops
+    from glfusion_amd.models.layers import BatchNorm2d, Conv2d, MaxPool2d, conv_bn_act, init_block_nhwc
+    n, h, w = shape
+    conv, bn, pool = Conv2d(1, 64, kernel_size=7, stride=1, padding=2), BatchNorm2d(64), MaxPool2d(kernel_size=3, stride=2, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(64, 1, 7, 7, seed=401) * 0.3); conv.bias.copy_(rnd(64, seed=402) * 0.2)
+        bn.weight.copy_(rnd(64, seed=403, lo=0.5, hi=1.5)); bn.bias.copy_(rnd(64, seed=404) * 0.5)
+        bn.running_mean.copy_(rnd(64, seed=405) * 0.3); bn.running_var.copy_(rnd(64, seed=406, lo=0.5, hi=2.0))
+    x = rnd(n, 1, h, w, seed=407)
+    want = F.max_pool2d(torch.relu(F.batch_norm(F.conv2d(x, conv.weight, conv.bias, 1, 2), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                                 False, 0.1, bn.eps)), 3, 2, 1).detach()
+    conv, bn = conv.to(DEV).eval(), bn.to(DEV).eval()
+    xd = _ops.to_nhwc(x.to(DEV))
+    for prec in ("f32", "f16x3"):
+        _ops.set_precision(prec)
+        try:
+            with torch.no_grad():
+                fused = init_block_nhwc(xd, conv, bn, pool)
+                _ops.FUSED_STEM = False
+                chain = init_block_nhwc(xd, conv, bn, pool)
+                _ops.FUSED_STEM = True
+            torch.cuda.synchronize()
+            assert fused.shape == chain.shape == (n, (h - 2 - 1) // 2 + 1, (w - 2 - 1) // 2 + 1, 64)
+            assert torch.equal(fused, chain)
+            np.testing.assert_allclose(fused.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+            if prec == "f16x3":
+                assert float(_ops.amax_of(fused)) == float(fused.abs().max())
+        finally:
+            _ops.FUSED_STEM = True
+            _ops.set_precision("f32")
+    # training mode and grad mode keep the differentiable chain
+    bn.train()
+    with torch.no_grad():
+        assert init_block_nhwc(xd, conv, bn, pool).shape == fused.shape
+    from glfusion_amd._lib import lib
+    assert lib.glf_stem7x7_bn_relu_pool(xd.data_ptr(), conv.weight.data_ptr(), None, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                        bn.weight.data_ptr(), bn.bias.data_ptr(), fused.data_ptr(), n, h, w, 32, 2, None, None) != 0
+    assert lib.glf_stem7x7_bn_relu_pool(None, conv.weight.data_ptr(), None, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                        bn.weight.data_ptr(), bn.bias.data_ptr(), fused.data_ptr(), n, h, w, 64, 2, None, None) != 0
+
+
 def test_mfma_probe_counts_what_it_claims():
     """glf_probe_mfma_f16 (bench.py's in-run power-limited peak): with constant operands (seed 0: all ones) every accumulator
     element grows by K = 16 per MFMA, so each thread stores 16 elements x 4 accumulators x 16 x iters -- the launch really
