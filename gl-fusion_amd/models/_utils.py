@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .layers import Conv2d
+from .layers import Conv2d, init_block_nhwc
 
 
 class IntermediateLayerGetter(nn.ModuleDict):
@@ -51,7 +51,7 @@ class _SimpleSegmentationModel_iekd(nn.Module):
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         hw = x.shape[-2:]
         bb = self.backbone
-        f = bb["maxpool"](bb["relu"](bb["bn1"](bb["conv1"](x))))
+        f = ops.from_nhwc(init_block_nhwc(ops.to_nhwc(x), bb["conv1"], bb["bn1"], bb["maxpool"]))     # one launch under no_grad evaluation
         for name in ("layer1", "layer2", "layer3", "layer4"):
             f = bb[name](f)
         logits = self.classifier(f)
