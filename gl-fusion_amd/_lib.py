@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("a_presplit", C.c_int32), ("b_presplit", C.c_int32),
         ("precision", C.c_int32),
         ("colmax", C.c_void_p),
+        ("c_dtype", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

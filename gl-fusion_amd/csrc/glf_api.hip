@@ -8,6 +8,7 @@ namespace glf {
 
 int init_gemm_attrs();   // gemm_f32.hip
 int init_attn_attrs();   // attn_softmax.hip
+int init_gemm_s16_attrs();   // gemm_s16.hip
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -94,6 +95,7 @@ int ensure_init() {
         st.cus = prop.multiProcessorCount;
         if (int rc = init_gemm_attrs()) return rc;           // hipFuncSetAttribute is per device
         if (int rc = init_attn_attrs()) return rc;
+        if (int rc = init_gemm_s16_attrs()) return rc;
         e = hipMalloc(reinterpret_cast<void**>(&st.zeros), ZERO_PAGE_FLOATS * sizeof(float));
         if (e == hipSuccess) e = hipMemset(st.zeros, 0, ZERO_PAGE_FLOATS * sizeof(float));
         if (e != hipSuccess) return fail(GLF_ERR_WORKSPACE, "hipMalloc(zero page): %s", hipGetErrorString(e));
@@ -106,7 +108,7 @@ int ensure_init() {
 }  // namespace glf
 
 extern "C" const char* glf_last_error(void) { return glf::err_buf(); }
-extern "C" int glf_abi_version(void) { return 6; }
+extern "C" int glf_abi_version(void) { return 7; }
 extern "C" int glf_init(void) { return glf::ensure_init(); }
 extern "C" size_t glf_sizeof_gemm_params(void) { return sizeof(glf_gemm_params); }
 extern "C" int glf_set_precision(int mode) {

@@ -44,6 +44,9 @@ typedef enum {
     GLF_ERR_NULL = -5
 } glf_status;
 
+/* Element type tags of the typed ("_t") and 16-bit-storage ("glf_s16_") entry points. */
+typedef enum { GLF_DT_F32 = 0, GLF_DT_BF16 = 1 } glf_dtype;
+
 const char* glf_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int glf_abi_version(void);
@@ -143,6 +146,8 @@ typedef struct {
                                 /* raises colmax[n] to the largest |C[m][n]| it stores -- with the batch statistics it bounds */
                                 /* the BatchNorm OUTPUT's maximum before that output exists (glf_bn_apply_from_sums         */
                                 /* packed_y: the activation written once, as the packed image its consumer reads)           */
+    int32_t c_dtype;            /* glf_s16_gemm_nt / _tn only: element type of C (GLF_DT_F32 or GLF_DT_BF16); the fp32-storage    */
+    int32_t reserved0;          /* entry points ignore it (C is fp32).  reserved0: padding, leave 0.                              */
 } glf_gemm_params;
 
 /* *out = max |x| over the [rows, cols] view with row stride ld (elements); out is a device float. */
@@ -172,6 +177,28 @@ int glf_gemm_tn(const float* A, const float* B, float* C,
                 const glf_gemm_params* p, glf_stream_t stream);
 /* bytes of glf_gemm_params.workspace the two-stage reduction of this call needs (0 when p->split <= 1). */
 size_t glf_gemm_tn_workspace_bytes(const glf_gemm_params* p);
+
+/* ---------------------------------------------------------------------------------------
+ * 16-bit storage ("S16": BASELINE.json configs[2] and [4] -- bf16 activations, saved tensors and
+ * activation gradients in HBM, fp32 master weights, fp32 accumulate).  Same contraction
+ * semantics and parameter block as glf_gemm_nt / glf_gemm_tn with these differences:
+ *   - A and B hold bf16 (row / batch / tap strides multiples of 8 elements, 16-byte aligned);
+ *     C holds p->c_dtype (activations: GLF_DT_BF16, weight gradients: GLF_DT_F32);
+ *   - ONE v_mfma_f32_32x32x16_bf16 per product; operands go global -> LDS by LDS-DMA
+ *     (global_load_lds_dwordx4), padding / overhang rows come from the library's zero page;
+ *   - K % 64 == 0 (NT); M % 8 == 0 and N % 8 == 0 (TN); rect = 0 or 2 (NT region mode); no
+ *     amax / presplit / precision fields (ignored); colstats is honoured by glf_s16_gemm_nt
+ *     (sums of the fp32 results before they are rounded to bf16);
+ *   - glf_s16_gemm_tn with split > 1 REQUIRES the workspace (glf_s16_gemm_tn_workspace_bytes):
+ *     slices store partial slabs, a second kernel adds them in slice order (no atomics).
+ * Replaces (reference call sites): the same convolutions / projections as glf_gemm_*, i.e.
+ * torchvision Bottleneck convs (ours.py:1797-1800), ASPP / head convs (deeplabv3.py:102-166),
+ * TPAVI theta/phi/g/W_z and the attention matmuls (ours.py:866-908), run under the bf16
+ * configuration the reference itself never had.
+ * ------------------------------------------------------------------------------------- */
+int glf_s16_gemm_nt(const void* A, const void* B, const float* bias, void* C, const glf_gemm_params* p, glf_stream_t stream);
+int glf_s16_gemm_tn(const void* A, const void* B, void* C, const glf_gemm_params* p, glf_stream_t stream);
+size_t glf_s16_gemm_tn_workspace_bytes(const glf_gemm_params* p);
 
 /* ---------------------------------------------------------------------------------------
  * Convolution entry points (F.conv2d forward / backward: models/_utils.py:192 excluded -- glf_stem7x7_* --,

@@ -22,7 +22,7 @@ def test_header_parses_and_library_exports_every_symbol():
     for name in protos:
         assert hasattr(dll, name), f"libglfusion_hip.so does not export {name}"
     dll.glf_abi_version.restype = ctypes.c_int
-    assert dll.glf_abi_version() == 6
+    assert dll.glf_abi_version() == 7
     # pure host-side queries work without a GPU
     dll.glf_bn_workspace.restype = ctypes.c_size_t
     dll.glf_bn_workspace.argtypes = [ctypes.c_int, ctypes.c_int]
