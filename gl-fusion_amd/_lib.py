@@ -66,13 +66,13 @@ class WeightJob(C.Structure):
                 ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("reserved", C.c_int32), ("first_wg", C.c_int64)]
 
 
-WJ_COPY, WJ_AMAX, WJ_TAP_MAJOR, WJ_TAP_MAJOR_T, WJ_TRANSPOSE, WJ_PACK, WJ_ZERO, WJ_PASSES = 0, 1, 2, 3, 4, 5, 6, 4
-WJ_PASS_OF = {WJ_COPY: 0, WJ_ZERO: 0, WJ_AMAX: 1, WJ_TAP_MAJOR: 2, WJ_TAP_MAJOR_T: 2, WJ_TRANSPOSE: 2, WJ_PACK: 3}
+WJ_COPY, WJ_AMAX, WJ_TAP_MAJOR, WJ_TAP_MAJOR_T, WJ_TRANSPOSE, WJ_PACK, WJ_ZERO, WJ_CVT_BF16, WJ_PASSES = 0, 1, 2, 3, 4, 5, 6, 7, 4
+WJ_PASS_OF = {WJ_COPY: 0, WJ_ZERO: 0, WJ_AMAX: 1, WJ_TAP_MAJOR: 2, WJ_TAP_MAJOR_T: 2, WJ_TRANSPOSE: 2, WJ_PACK: 3, WJ_CVT_BF16: 3}
 
 
 _SCALARS = {
     "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
-    "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None, "uint8_t": C.c_uint8, "uint32_t": C.c_uint32,
+    "size_t": C.c_size_t, "glf_stream_t": C.c_void_p, "void": None, "uint8_t": C.c_uint8, "uint32_t": C.c_uint32, "int32_t": C.c_int32,
 }
 
 

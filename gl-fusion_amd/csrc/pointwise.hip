@@ -74,9 +74,16 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
 // 49 x Cout weights sit in LDS; each thread owns one pixel x 16 output channels per pass.
 // ---------------------------------------------------------------------------------------
 constexpr int ST = 16, SP = ST + 6;
-template <int COUT>
+// 16-bit storage (glf_s16_stem7x7_*): the conv output / its gradient are bf16; arithmetic stays fp32
+__device__ __forceinline__ unsigned stem_pack2(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
+template <int COUT, bool OUT16>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y, int h, int wd, int ho, int wo, int pad) {
+                                                       void* __restrict__ yv, int h, int wd, int ho, int wo, int pad) {
     __shared__ float patch[SP * SP];
     __shared__ __attribute__((aligned(16))) float wt[49 * COUT];       // [tap][co]
     __shared__ __attribute__((aligned(16))) float bs[COUT];
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) xin[ky * 7 + kx] = patch[(ty + ky) * SP + tx + kx];
     if (oy >= ho || ox >= wo) return;
-    float* dst = y + (((long long)n * ho + oy) * wo + ox) * COUT;
+    float* dst = static_cast<float*>(yv) + (((long long)n * ho + oy) * wo + ox) * COUT;
+    unsigned short* dst16 = static_cast<unsigned short*>(yv) + (((long long)n * ho + oy) * wo + ox) * COUT;
 #pragma unroll 1
     for (int c0 = 0; c0 < COUT; c0 += 16) {
         float4 a0 = *reinterpret_cast<const float4*>(bs + c0), a1 = *reinterpret_cast<const float4*>(bs + c0 + 4);
@@ -115,8 +123,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             a2.x = fmaf(v, w2.x, a2.x); a2.y = fmaf(v, w2.y, a2.y); a2.z = fmaf(v, w2.z, a2.z); a2.w = fmaf(v, w2.w, a2.w);
             a3.x = fmaf(v, w3.x, a3.x); a3.y = fmaf(v, w3.y, a3.y); a3.z = fmaf(v, w3.z, a3.z); a3.w = fmaf(v, w3.w, a3.w);
         }
-        *reinterpret_cast<float4*>(dst + c0) = a0; *reinterpret_cast<float4*>(dst + c0 + 4) = a1;
-        *reinterpret_cast<float4*>(dst + c0 + 8) = a2; *reinterpret_cast<float4*>(dst + c0 + 12) = a3;
+        if (OUT16) {
+            *reinterpret_cast<uint4*>(dst16 + c0) = make_uint4(stem_pack2(a0.x, a0.y), stem_pack2(a0.z, a0.w), stem_pack2(a1.x, a1.y), stem_pack2(a1.z, a1.w));
+            *reinterpret_cast<uint4*>(dst16 + c0 + 8) = make_uint4(stem_pack2(a2.x, a2.y), stem_pack2(a2.z, a2.w), stem_pack2(a3.x, a3.y), stem_pack2(a3.z, a3.w));
+        } else {
+            *reinterpret_cast<float4*>(dst + c0) = a0; *reinterpret_cast<float4*>(dst + c0 + 4) = a1;
+            *reinterpret_cast<float4*>(dst + c0 + 8) = a2; *reinterpret_cast<float4*>(dst + c0 + 12) = a3;
+        }
     }
 }
 
@@ -124,8 +137,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // One workgroup = one 16x16 output tile of one image; thread = (co = tid & 63, tap group = tid >> 6).
 // partial[block][50][64] (49 taps + bias row), folded by stem_wgrad_finalize.
 constexpr int STEM_CO = 64;
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+template <bool DY16>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const void* __restrict__ dyv, float* __restrict__ partial,
                                                          int h, int wd, int ho, int wo, int pad) {
+    const float* __restrict__ dy = static_cast<const float*>(dyv);
+    const unsigned short* __restrict__ dy16 = static_cast<const unsigned short*>(dyv);
     __shared__ float patch[SP * SP];
     const int tid = threadIdx.x;
     const int n = blockIdx.z, oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
@@ -143,7 +159,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const int ny = min(ST, ho - oy0), nx = min(ST, wo - ox0);
     for (int py = 0; py < ny; ++py)
         for (int px = 0; px < nx; ++px) {
-            const float g = dy[(((long long)n * ho + oy0 + py) * wo + ox0 + px) * STEM_CO + co];
+            const long long go = (((long long)n * ho + oy0 + py) * wo + ox0 + px) * STEM_CO + co;
+            const float g = DY16 ? __uint_as_float((unsigned)dy16[go] << 16) : dy[go];
             accb += g;
 #pragma unroll
             for (int i = 0; i < 13; ++i) {
@@ -561,8 +578,20 @@ extern "C" int glf_stem7x7_fwd(const float* x, const float* w, const float* bias
     GLF_REQUIRE(n > 0 && n <= 65535 && ho > 0 && wo > 0 && pad >= 0 && pad <= 3, GLF_ERR_BAD_SHAPE, "stem7x7_fwd: bad shape");
     GLF_REQUIRE(al16(y), GLF_ERR_BAD_SHAPE, "stem7x7_fwd: y must be 16-byte aligned");
     dim3 grid((wo + ST - 1) / ST, (ho + ST - 1) / ST, n);
-    hipLaunchKernelGGL((stem_fwd_kernel<STEM_CO>), grid, dim3(256), 0, glf::S(s), x, w, bias, y, h, wdt, ho, wo, pad);
+    hipLaunchKernelGGL((stem_fwd_kernel<STEM_CO, false>), grid, dim3(256), 0, glf::S(s), x, w, bias, y, h, wdt, ho, wo, pad);
     return glf::check_launch("stem7x7_fwd");
+}
+extern "C" int glf_s16_stem7x7_fwd(const float* x, const float* w, const float* bias, void* y,
+                                   int n, int h, int wdt, int cout, int pad, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && w && y, GLF_ERR_NULL, "s16_stem7x7_fwd: null argument");
+    GLF_REQUIRE(cout == STEM_CO, GLF_ERR_UNSUPPORTED, "stem7x7: Cout must be 64 (got %d)", cout);
+    const int ho = h + 2 * pad - 6, wo = wdt + 2 * pad - 6;
+    GLF_REQUIRE(n > 0 && n <= 65535 && ho > 0 && wo > 0 && pad >= 0 && pad <= 3, GLF_ERR_BAD_SHAPE, "s16_stem7x7_fwd: bad shape");
+    GLF_REQUIRE(al16(y), GLF_ERR_BAD_SHAPE, "s16_stem7x7_fwd: y must be 16-byte aligned");
+    dim3 grid((wo + ST - 1) / ST, (ho + ST - 1) / ST, n);
+    hipLaunchKernelGGL((stem_fwd_kernel<STEM_CO, true>), grid, dim3(256), 0, glf::S(s), x, w, bias, y, h, wdt, ho, wo, pad);
+    return glf::check_launch("s16_stem7x7_fwd");
 }
 // Inference-mode stem in ONE kernel: conv7x7 (Cin = 1) + bias -> BatchNorm (given mean / invstd: the running statistics) -> ReLU ->
 // max-pool 3x3 stride 2 pad 1.  One workgroup = a 16 x 16 tile of conv outputs starting one row / column before an even
@@ -681,11 +710,25 @@ extern "C" int glf_stem7x7_wgrad(const float* x, const float* dy, float* dw, flo
     const int ho = h + 2 * pad - 6, wo = wdt + 2 * pad - 6;
     GLF_REQUIRE(n > 0 && n <= 65535 && ho > 0 && wo > 0 && pad >= 0 && pad <= 3, GLF_ERR_BAD_SHAPE, "stem7x7_wgrad: bad shape");
     dim3 grid((wo + ST - 1) / ST, (ho + ST - 1) / ST, n);
-    hipLaunchKernelGGL(stem_wgrad_kernel, grid, dim3(256), 0, glf::S(s), x, dy, partial, h, wdt, ho, wo, pad);
+    hipLaunchKernelGGL(stem_wgrad_kernel<false>, grid, dim3(256), 0, glf::S(s), x, dy, partial, h, wdt, ho, wo, pad);
     if (int rc = glf::check_launch("stem7x7_wgrad")) return rc;
     const long long nblk = (long long)grid.x * grid.y * grid.z;
     hipLaunchKernelGGL(stem_wgrad_finalize, dim3(50), dim3(1024), 0, glf::S(s), partial, nblk, dw, db);
     return glf::check_launch("stem7x7_wgrad_finalize");
+}
+extern "C" int glf_s16_stem7x7_wgrad(const float* x, const void* dy, float* dw, float* db, float* partial,
+                                     int n, int h, int wdt, int cout, int pad, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x && dy && dw && partial, GLF_ERR_NULL, "s16_stem7x7_wgrad: null argument");
+    GLF_REQUIRE(cout == STEM_CO, GLF_ERR_UNSUPPORTED, "stem7x7: Cout must be 64 (got %d)", cout);
+    const int ho = h + 2 * pad - 6, wo = wdt + 2 * pad - 6;
+    GLF_REQUIRE(n > 0 && n <= 65535 && ho > 0 && wo > 0 && pad >= 0 && pad <= 3, GLF_ERR_BAD_SHAPE, "s16_stem7x7_wgrad: bad shape");
+    dim3 grid((wo + ST - 1) / ST, (ho + ST - 1) / ST, n);
+    hipLaunchKernelGGL(stem_wgrad_kernel<true>, grid, dim3(256), 0, glf::S(s), x, dy, partial, h, wdt, ho, wo, pad);
+    if (int rc = glf::check_launch("s16_stem7x7_wgrad")) return rc;
+    const long long nblk = (long long)grid.x * grid.y * grid.z;
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3(50), dim3(1024), 0, glf::S(s), partial, nblk, dw, db);
+    return glf::check_launch("s16_stem7x7_wgrad_finalize");
 }
 
 extern "C" int glf_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, glf_stream_t s) {

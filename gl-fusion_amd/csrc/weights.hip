@@ -103,6 +103,22 @@ __device__ __forceinline__ void job_pack(const glf_weight_job& j, long long wg) 
     }
 }
 
+// dst (bf16) = round-to-nearest-even(src), d0 elements (a multiple of 4; src 16-byte, dst 8-byte aligned): the operand images of
+// the 16-bit-storage contractions (glf_s16_gemm_*), made from the fp32 master weights once per update
+__device__ __forceinline__ void job_cvt_bf16(const glf_weight_job& j, long long wg) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const long long n = j.d0, base = wg * ELEMS_PER_WG;
+    const long long hi = base + ELEMS_PER_WG < n ? base + ELEMS_PER_WG : n;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
+    for (long long i = base + 4 * threadIdx.x; i < hi; i += 4 * WB) {
+        const float4 v = *reinterpret_cast<const float4*>(j.src + i);
+        const f32x2_ a = {v.x, v.y}, b = {v.z, v.w};
+        *reinterpret_cast<uint2*>(dst + i) = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_)),
+                                                        __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_)));
+    }
+}
+
 __global__ __launch_bounds__(WB) void weights_refresh_kernel(const glf_weight_job* __restrict__ jobs, int first, int count) {
     // job of this workgroup: the last one whose first_wg <= blockIdx.x
     int lo = 0, hi = count - 1;
@@ -121,13 +137,14 @@ __global__ __launch_bounds__(WB) void weights_refresh_kernel(const glf_weight_jo
         case GLF_WJ_TRANSPOSE: job_transpose(j, wg); break;
         case GLF_WJ_PACK: job_pack(j, wg); break;
         case GLF_WJ_ZERO: job_zero(j, wg); break;
+        case GLF_WJ_CVT_BF16: job_cvt_bf16(j, wg); break;
         default: break;
     }
 }
 
 long long job_workgroups(const glf_weight_job& j) {
     switch (j.kind) {
-        case GLF_WJ_COPY: case GLF_WJ_AMAX: case GLF_WJ_PACK: case GLF_WJ_ZERO: return ((long long)j.d0 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
+        case GLF_WJ_COPY: case GLF_WJ_AMAX: case GLF_WJ_PACK: case GLF_WJ_ZERO: case GLF_WJ_CVT_BF16: return ((long long)j.d0 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
         case GLF_WJ_TAP_MAJOR: case GLF_WJ_TAP_MAJOR_T: return ((long long)j.d0 * j.d1 * j.d2 + ELEMS_PER_WG - 1) / ELEMS_PER_WG;
         case GLF_WJ_TRANSPOSE: return (long long)((j.d0 + 31) / 32) * ((j.d1 + 31) / 32);
         default: return -1;
@@ -145,12 +162,15 @@ extern "C" int glf_weights_plan(glf_weight_job* jobs_host, int n_jobs, int* pass
         GLF_REQUIRE(j.pass >= 0 && j.pass < GLF_WJ_PASSES && j.pass >= prev, GLF_ERR_BAD_SHAPE,
                     "weights_plan: job %d: pass %d out of range or jobs not sorted by pass", i, j.pass);
         GLF_REQUIRE((j.src || j.kind == GLF_WJ_ZERO) && (j.dst || j.kind == GLF_WJ_AMAX), GLF_ERR_NULL, "weights_plan: job %d: null tensor", i);
-        GLF_REQUIRE(j.d0 > 0 && (j.kind == GLF_WJ_COPY || j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK || j.kind == GLF_WJ_ZERO || j.d1 > 0), GLF_ERR_BAD_SHAPE,
+        GLF_REQUIRE(j.d0 > 0 && (j.kind == GLF_WJ_COPY || j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK || j.kind == GLF_WJ_ZERO || j.kind == GLF_WJ_CVT_BF16 || j.d1 > 0), GLF_ERR_BAD_SHAPE,
                     "weights_plan: job %d: bad extents", i);
         if (j.kind == GLF_WJ_AMAX || j.kind == GLF_WJ_PACK) GLF_REQUIRE(j.amax, GLF_ERR_NULL, "weights_plan: job %d needs an amax scalar", i);
         if (j.kind == GLF_WJ_PACK)
             GLF_REQUIRE((j.d0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 15u) == 0, GLF_ERR_BAD_SHAPE,
                         "weights_plan: job %d: packed images need 16-byte aligned tensors of 4n elements", i);
+        if (j.kind == GLF_WJ_CVT_BF16)
+            GLF_REQUIRE((j.d0 & 3) == 0 && (reinterpret_cast<uintptr_t>(j.src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(j.dst) & 7u) == 0, GLF_ERR_BAD_SHAPE,
+                        "weights_plan: job %d: bf16 images need aligned tensors of 4n elements", i);
         if (j.kind == GLF_WJ_TAP_MAJOR || j.kind == GLF_WJ_TAP_MAJOR_T) GLF_REQUIRE(j.d2 > 0, GLF_ERR_BAD_SHAPE, "weights_plan: job %d: taps must be > 0", i);
         const long long w = job_workgroups(j);
         GLF_REQUIRE(w > 0, GLF_ERR_UNSUPPORTED, "weights_plan: job %d: unknown kind %d", i, j.kind);

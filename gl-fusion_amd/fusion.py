@@ -325,7 +325,11 @@ def tpavi_forward(x5: torch.Tensor, mod) -> torch.Tensor:
     training = bn.training
     if training and bn.momentum is None:
         raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")
-    return TpaviFn.apply(
+    fn = TpaviFn
+    if x5.dtype == torch.bfloat16:
+        from .ops16 import Tpavi16Fn
+        fn = Tpavi16Fn
+    return fn.apply(
         x5, mod.theta.weight, mod.theta.bias, mod.phi.weight, mod.phi.bias, mod.g.weight, mod.g.bias,
         mod.W_z[0].weight, mod.W_z[0].bias, bn.weight, bn.bias, mod.norm_layer.weight, mod.norm_layer.bias,
         bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None,

@@ -81,7 +81,7 @@ class ASPP(nn.Module):
         # the 1280 -> 256 projection is a single K = 1280 contraction (and one dgrad, one wgrad) -- still no concat copy
         n, h, w = x.shape[0], x.shape[1], x.shape[2]
         widths = [conv[0].out_channels if not isinstance(conv, ASPPPooling) else conv[1].out_channels for conv in self.convs]
-        cat = torch.empty(n, h, w, sum(widths), dtype=torch.float32, device=x.device)
+        cat = torch.empty(n, h, w, sum(widths), dtype=x.dtype, device=x.device)
         slot = ops.amax_slot(x.device)
         branches, off = [], 0
         for conv, xi, ck in zip(self.convs, xs, widths):
@@ -91,6 +91,12 @@ class ASPP(nn.Module):
             else:
                 branches.append(conv.forward_nhwc(xi))
             off += ck
+        pbn = self.project[1]
+        if ops.s16() and _CAT_BUFFER and (pbn.training or pbn.running_mean is None):
+            # 16-bit storage: the projection's BatchNorm statistics come out of its own epilogue
+            sums = ops.stats_slot(self.project[0].out_channels, x.device)
+            y = ops.conv1x1_cat(self.project[0].weight, branches, colstats=sums)
+            return pbn.forward_nhwc(y, relu=True, sums=sums)
         y = ops.conv1x1_cat(self.project[0].weight, branches)
         # (the projection's gradient is consumed by ConvCatFn's dgrad / wgrad only -- and only its single-buffer form reads it packed)
         pg = _CAT_BUFFER and torch.is_grad_enabled() and ops.takes_packed_grad(self.project[0].weight)

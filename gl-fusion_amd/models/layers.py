@@ -95,7 +95,7 @@ def conv_bn_act(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual=None, con
     pg = (not stem) and conv.bias is None and torch.is_grad_enabled() and ops.takes_packed_grad(conv.weight)
     if training and FUSE_BN_STATS and not stem:
         stride, pad, dil = conv._geom()
-        if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2]):
+        if ops.conv_stats_fusable(conv.weight, stride, pad, dil, x.shape[1], x.shape[2], x.dtype):
             sums = ops.stats_slot(conv.out_channels, x.device)
             po = consumer is not None and residual is None and ops.takes_packed_input(consumer.weight)
             if po:
@@ -109,7 +109,7 @@ def init_block_nhwc(x, conv: Conv2d, bn: BatchNorm2d, pool: MaxPool2d):
     no_grad with running statistics: ONE launch (glf_stem7x7_bn_relu_pool; the conv output never reaches memory).  Training, or any
     call that records a graph: conv -> BatchNorm (batch statistics) -> ReLU -> max-pool as three kernels with their backward."""
     stride, pad, dil = conv._geom()
-    fused = (ops.FUSED_STEM and not torch.is_grad_enabled() and not (bn.training or bn.running_mean is None)
+    fused = (ops.FUSED_STEM and not ops.s16() and not torch.is_grad_enabled() and not (bn.training or bn.running_mean is None)
              and conv.in_channels == 1 and conv.out_channels == 64 and conv.kernel_size == (7, 7) and stride == 1 and dil == 1 and pad <= 3
              and (_one(pool.kernel_size), _one(pool.stride), _one(pool.padding), _one(pool.dilation)) == (3, 2, 1, 1) and not pool.ceil_mode)
     if fused:

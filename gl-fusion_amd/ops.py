@@ -124,6 +124,20 @@ def tap_mask(gather: int, hd: int, wd: int, hs: int, ws: int, kh: int, kw: int, 
 # contraction precision of the calls this module issues (index into PRECISIONS); passed PER CALL through
 # glf_gemm_params.precision, so nothing process-wide is touched in the library
 _PREC = [0]
+_S16 = [False]             # 16-bit storage mode ("bf16" precision): see glfusion_amd.ops16
+
+
+def s16() -> bool:
+    return _S16[0]
+
+
+def act_dtype() -> torch.dtype:
+    """dtype of the activations the engine keeps in HBM under the current precision."""
+    return torch.bfloat16 if _S16[0] else torch.float32
+
+
+def _is16(t) -> bool:
+    return isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16
 
 TWO_STAGE_SPLITK = os.environ.get("GLF_TWO_STAGE", "1") != "0"
 
@@ -1022,12 +1036,17 @@ class Conv2dFn(Function):
 
 
 def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1, colstats=None):
+    if _is16(x):
+        from . import ops16
+        return ops16.conv2d(x, weight, bias, stride, pad, dil, colstats)
     return Conv2dFn.apply(x, weight, bias, stride, pad, dil, colstats)
 
 
-def conv_stats_fusable(weight, stride: int, pad: int, dil: int, h: int, w: int) -> bool:
+def conv_stats_fusable(weight, stride: int, pad: int, dil: int, h: int, w: int, dtype=None) -> bool:
     """True when conv2d(..., colstats=) is honoured: f16x3 kernels (Cin % 32 == 0, Cout % 4 == 0) and the conv is not
     one that runs as per-tap rectangles with atomics (ASPP rate 12 / 24 forward)."""
+    if _S16[0]:                          # the 16-bit kernels always honour colstats (region mode stores every element once)
+        return dtype == torch.bfloat16 and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0
     if _PREC[0] < 2:
         return False
     cout, cin, kh, kw = weight.shape
@@ -1159,7 +1178,12 @@ class ConvCatFn(Function):
         return (dw.view(ctx.wshape) if dw is not None else None, db, *grads)
 
 
-def conv1x1_cat(weight, xs: Sequence[torch.Tensor], bias=None):
+def conv1x1_cat(weight, xs: Sequence[torch.Tensor], bias=None, colstats=None):
+    if _is16(xs[0]):
+        from . import ops16
+        return ops16.conv1x1_cat(weight, xs, bias, colstats)
+    if colstats is not None:
+        raise RuntimeError("glfusion_amd: conv1x1_cat honours colstats in 16-bit storage mode only")
     return ConvCatFn.apply(weight, bias, *xs)
 
 
@@ -1195,6 +1219,9 @@ class StemFn(Function):
 
 
 def stem7x7(x, weight, bias, pad: int):
+    if _S16[0]:                          # fp32 image in, bf16 conv output: the entry into the 16-bit domain
+        from . import ops16
+        return ops16.stem7x7(x, weight, bias, pad)
     return StemFn.apply(x, weight, bias, pad)
 
 
@@ -1423,6 +1450,16 @@ def batch_norm_act(x, bn: torch.nn.modules.batchnorm._BatchNorm, relu: bool, res
     if bn.momentum is None and training and bn.track_running_stats:
         raise RuntimeError("glfusion_amd: cumulative-average BatchNorm (momentum=None) is not built")
     track = training and bn.track_running_stats
+    if _is16(x):
+        from . import ops16
+        y = ops16.BatchNormAct16Fn.apply(x, bn.weight, bn.bias, residual,
+                                         bn.running_mean if (track or not training) else None,
+                                         bn.running_var if (track or not training) else None,
+                                         bn.num_batches_tracked if track else None,
+                                         training, momentum, float(bn.eps), relu, sums if training else None)
+        if BN_TAP is not None and track:
+            BN_TAP.append((bn,) + _last_bn[0])
+        return y
     y = BatchNormActFn.apply(x, bn.weight, bn.bias, residual,
                              bn.running_mean if (track or not training) else None,
                              bn.running_var if (track or not training) else None,
@@ -1456,6 +1493,9 @@ class ReluFn(Function):
 
 
 def relu(x):
+    if _is16(x):
+        from . import ops16
+        return ops16.Relu16Fn.apply(x)
     return ReluFn.apply(x)
 
 
@@ -1485,6 +1525,9 @@ def dropout(x, p: float, training: bool):
     if p >= 1.0:
         raise RuntimeError("dropout p must be < 1")
     seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62).item())   # host RNG: no device sync
+    if _is16(x):
+        from . import ops16
+        return ops16.Dropout16Fn.apply(x, float(p), seed)
     return DropoutFn.apply(x, float(p), seed)
 
 
@@ -1514,6 +1557,9 @@ class MaxPool3x3s2Fn(Function):
 
 
 def maxpool3x3s2(x):
+    if _is16(x):
+        from . import ops16
+        return ops16.MaxPool16Fn.apply(x)
     return MaxPool3x3s2Fn.apply(x)
 
 
@@ -1540,6 +1586,9 @@ class AvgPoolFn(Function):
 
 
 def global_avgpool(x):
+    if _is16(x):
+        from . import ops16
+        return ops16.AvgPool16Fn.apply(x)
     return AvgPoolFn.apply(x)
 
 
@@ -1571,6 +1620,9 @@ class BroadcastFn(Function):
 
 
 def broadcast_hw(x, h: int, w: int):
+    if _is16(x) or _S16[0]:             # 16-bit storage: the pooled branch arrives in fp32 and is broadcast into the bf16 buffer
+        from . import ops16
+        return ops16.Broadcast16Fn.apply(x, h, w)
     return BroadcastFn.apply(x, h, w)
 
 
@@ -1582,7 +1634,7 @@ class FanOutFn(Function):
     def forward(ctx, x, k: int, lazy: bool = False):
         ctx.k = k
         # lazy only when x really is a batch_norm_act output: its backward is the one node that understands `_glf_addend`
-        ctx.lazy = bool(lazy) and k == 2 and LAZY_FAN_IN and type(x.grad_fn).__name__ == "BatchNormActFnBackward"
+        ctx.lazy = bool(lazy) and k == 2 and LAZY_FAN_IN and type(x.grad_fn).__name__ in ("BatchNormActFnBackward", "BatchNormAct16FnBackward")
         outs = tuple(x.view_as(x) for _ in range(k))
         am = amax_of(x)                       # one measurement (or the producer's by-product) serves every alias
         share = [None]                        # ... and so does one pre-split image, whichever consumer makes it first
@@ -1605,6 +1657,9 @@ class FanOutFn(Function):
             a = live[0]
             a._glf_addend = live[1]
             return a, None, None
+        if _is16(live[0]):
+            from . import ops16
+            return ops16.add_n16(live), None, None
         out = torch.empty_like(live[0])
         n = out.numel()
         if n % 4 != 0 or any(d.shape != out.shape for d in live) or len(live) > 8:
@@ -1812,6 +1867,9 @@ class GateFn(Function):
 
 
 def local_gate(cls_logits, ctr_logits, f4, weight: float):
+    if _is16(f4):
+        from . import ops16
+        return ops16.Gate16Fn.apply(cls_logits, ctr_logits, f4, float(weight))[0]
     return GateFn.apply(cls_logits, ctr_logits, f4, float(weight))
 
 
@@ -1845,6 +1903,9 @@ class AxpbyFn(Function):
 
 
 def axpby(x, y, a: float, b: float):
+    if _is16(x):
+        from . import ops16
+        return ops16.Axpby16Fn.apply(x, y, float(a), float(b))
     return AxpbyFn.apply(x, y, float(a), float(b))
 
 
@@ -1867,6 +1928,11 @@ class GateMapFn(GateFn):
 
 
 def local_gate_with_map(cls_logits, ctr_logits, f4, weight: float):
+    if _is16(f4):
+        from . import ops16
+        y, a = ops16.Gate16Fn.apply(cls_logits, ctr_logits, f4, float(weight))
+        n, h, w = f4.shape[0], f4.shape[1], f4.shape[2]
+        return y, a.view(n, 1, h, w).clone()
     return GateMapFn.apply(cls_logits, ctr_logits, f4, float(weight))
 
 
@@ -1913,6 +1979,9 @@ class StackViewsFn(Function):
 
 
 def stack_views(xs: Sequence[torch.Tensor]):
+    if _is16(xs[0]):
+        from . import ops16
+        return ops16.StackViews16Fn.apply(*xs)
     return StackViewsFn.apply(*xs)
 
 
@@ -1948,6 +2017,9 @@ class AddViewsFn(Function):
 
 
 def add_views(g, l):
+    if _is16(g):
+        from . import ops16
+        return ops16.AddViews16Fn.apply(g, l)
     return AddViewsFn.apply(g, l)
 
 
@@ -1981,6 +2053,9 @@ class SplitViewsFn(Function):
 
 
 def split_views(g):
+    if _is16(g):
+        from . import ops16
+        return ops16.SplitViews16Fn.apply(g)
     return SplitViewsFn.apply(g)
 
 
@@ -2010,6 +2085,9 @@ class BilinearUpFn(Function):
 
 
 def bilinear_up(x, ho: int, wo: int):
+    if _is16(x):
+        from . import ops16
+        x = ops16.to_f32(x)
     return BilinearUpFn.apply(x, ho, wo)
 
 
@@ -2088,6 +2166,9 @@ class SumHWFn(Function):
 
 
 def sum_hw(x: torch.Tensor) -> torch.Tensor:
+    if _is16(x):                          # the cycle loss works on fp32 features (main.py:226): one cast of the pooled block's input
+        from . import ops16
+        x = ops16.to_f32(_contig(x))
     return SumHWFn.apply(x)
 
 
@@ -2148,14 +2229,18 @@ def dense_seg_cycle(feat, target_region: int = 16, cyc_off: int = 2, chunk_size:
 
 # contraction precision: "f32" = exact fp32 MFMA, "bf16x6" = split-bf16 (6 MFMAs per product),
 # "f16x3" = scaled split-fp16 (3 MFMAs per product).  Host-side setting handed to the library with every call.
-PRECISIONS = ("f32", "bf16x6", "f16x3", "f16")
+# "bf16" = 16-bit STORAGE (BASELINE configs 3 / 5): bf16 activations / saved tensors / activation gradients in HBM, one bf16 MFMA
+# per product (glfusion_amd.ops16); the few fp32 contractions left in that mode (5- / 1-channel head logits) use the exact kernels.
+PRECISIONS = ("f32", "bf16x6", "f16x3", "f16", "bf16")
 # ----------------------------------------------------------------------------------------
 def set_precision(mode: str) -> None:
-    _PREC[0] = PRECISIONS.index(mode)
+    i = PRECISIONS.index(mode)
+    _S16[0] = mode == "bf16"
+    _PREC[0] = 0 if _S16[0] else i
 
 
 def get_precision() -> str:
-    return PRECISIONS[_PREC[0]]
+    return "bf16" if _S16[0] else PRECISIONS[_PREC[0]]
 
 
 class precision_scope:

@@ -1,0 +1,800 @@
+"""16-bit-storage ("S16") autograd nodes: BASELINE.json configs[2] / [4] -- bf16 activations, saved-for-backward tensors and
+activation gradients in HBM, fp32 master weights and weight gradients, fp32 MFMA accumulation.
+
+`ops.set_precision("bf16")` selects the mode; the public functions of glfusion_amd.ops dispatch here on the tensor's dtype
+(torch.bfloat16), so the model code is the same for every precision.  Every function launches glf_s16_* kernels from
+libglfusion_hip.so on the current HIP stream; nothing here is a torch compute op and there is no fallback.
+
+What stays fp32 in this mode: the input images, the 5- / 1-channel head logits and everything after them (bilinear
+up-sampling, loss, metrics), per-channel statistics and every parameter / parameter gradient.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import GemmParams, WJ_CVT_BF16, check, lib
+from . import ops as _o
+
+BF = torch.bfloat16
+_p, _stream, _contig = _o._p, _o._stream, _o._contig
+DT_F32, DT_BF16 = 0, 1
+
+
+def _chk16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != BF:
+        raise RuntimeError(f"glfusion_amd: {name} must be a CUDA(HIP) bfloat16 tensor in 16-bit storage mode (got "
+                           f"{getattr(t, 'device', None)}, {getattr(t, 'dtype', None)}). The engine has no CPU fallback.")
+    return t
+
+
+def weight16(layout: torch.Tensor, owner: torch.Tensor, tag: str) -> torch.Tensor:
+    """bf16 image of a dense fp32 weight layout derived from the parameter `owner` (tap-major / transposed / stacked forms of
+    ops.tap_major & co), made once per weight update: a registered job of the multi-tensor refresh (GLF_WJ_CVT_BF16)."""
+    n = layout.numel()
+    if n % 8 != 0 or not layout.is_contiguous():
+        raise RuntimeError("glfusion_amd: a 16-bit weight image needs a contiguous layout of 8n elements")
+    im, fresh = _o._wimage(owner, "s16:" + tag, WJ_CVT_BF16, layout, (n, 0, 0), lambda: torch.empty(layout.shape, dtype=BF, device=layout.device))
+    if fresh:
+        check(lib.glf_s16_cast(_p(layout), DT_F32, _p(im.dst), DT_BF16, n, _stream()), "s16_cast(weight)")
+    return im.dst
+
+
+KERNEL_NAMES = {("nt", False): "s16_rows_kernel<false>", ("nt", True): "s16_rows_kernel<true>",
+                ("tn", False): "s16_tn_kernel<false>", ("tn", True): "s16_tn_kernel<true>"}
+
+
+def gemm16(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
+           bias: Optional[torch.Tensor] = None, taps: int = 1, mask: int = 1, tap_stride_b: int = 0, gather: int = 0, geo=None,
+           batch: int = 1, bsa: int = 0, bsb: int = 0, bsc: int = 0, alpha: float = 1.0, accumulate: bool = False, split: int = 1,
+           rect: int = 0, colstats: Optional[torch.Tensor] = None) -> None:
+    """glf_s16_gemm_nt / glf_s16_gemm_tn (include/glfusion.h).  A, B: bf16; Cm: bf16 or fp32 (its dtype is what is stored)."""
+    p = GemmParams()
+    p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+    p.taps, p.tap_mask, p.tap_stride_b, p.gather = taps, mask, tap_stride_b, gather
+    (p.n_img, p.hs, p.ws, p.hd, p.wd, p.kh, p.kw, p.stride, p.pad, p.dil) = geo if geo is not None else (1, 1, 1, 1, 1, 1, 1, 1, 0, 1)
+    p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch, bsa, bsb, bsc
+    p.alpha, p.accumulate, p.split, p.rect = alpha, int(accumulate), split, int(rect)
+    p.colstats = _p(colstats)
+    p.c_dtype = DT_BF16 if Cm.dtype == BF else DT_F32
+    ws = None
+    if mode == "tn" and split > 1:
+        nbytes = int(lib.glf_s16_gemm_tn_workspace_bytes(C.byref(p)))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=Cm.device)
+        p.workspace, p.workspace_bytes = _p(ws), nbytes
+    prof = _o.PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    if mode == "nt":
+        check(lib.glf_s16_gemm_nt(_p(A), _p(B), _p(bias), _p(Cm), C.byref(p), _stream()), "s16_gemm_nt")
+    elif mode == "tn":
+        check(lib.glf_s16_gemm_tn(_p(A), _p(B), _p(Cm), C.byref(p), _stream()), "s16_gemm_tn")
+    else:
+        raise ValueError(mode)
+    if prof is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        kept = bin(mask).count("1")
+        dense = 2.0 * M * N * K * taps * batch
+        src_rows = (geo[0] * geo[1] * geo[2]) if geo else None
+        in_range = _o.rect_fraction(gather, geo[3], geo[4], geo[1], geo[2], geo[5], geo[6], geo[8], geo[9], mask) if (rect and geo and gather) else 1.0
+        csz = 2 if Cm.dtype == BF else 4
+        if mode == "tn":
+            abytes = batch * (2.0 * (K * M + (src_rows if src_rows else K) * N) + csz * M * N * kept)
+        else:
+            abytes = batch * (2.0 * ((src_rows if src_rows else M) * K + N * K * kept) + csz * M * N * (2 if accumulate else 1))
+        prof.append((KERNEL_NAMES[(mode, gather != 0)], dense, dense * kept / taps * in_range, ev0, ev1,
+                     (M, N, K, taps, kept, batch, split, geo[8] if geo else 0, geo[9] if geo else 0), abytes))
+
+
+def tn_split16(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
+    """Reduction slices of glf_s16_gemm_tn: 256 x 128 tiles, one workgroup per CU; aim for ~2 rounds of the 256 CUs, keep at
+    least 512 rows per slice (every slice costs an [M][N] fp32 slab written and read back)."""
+    tiles = ((m + 255) // 256) * ((n + 127) // 128) * max(ntaps, 1) * batch
+    want = max(1, (512 + tiles - 1) // tiles)
+    cap = max(1, rows // 512)
+    return int(max(1, min(want, cap, 65535 // max(batch, 1))))
+
+
+def s16_conv_ok(cin: int, cout: int) -> bool:
+    """A convolution runs on the 16-bit kernels when forward (K = Cin), dgrad (K = Cout) and wgrad (M = Cout, N = Cin) all fit."""
+    return cin % 64 == 0 and cout % 64 == 0
+
+
+# ----------------------------------------------------------------------------------------
+# casts at the border of the 16-bit domain
+# ----------------------------------------------------------------------------------------
+class ToF32Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk16(x, "cast input"))
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        check(lib.glf_s16_cast(_p(x), DT_BF16, _p(y), DT_F32, x.numel(), _stream()), "s16_cast")
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _contig(dy)
+        dx = torch.empty(dy.shape, dtype=BF, device=dy.device)
+        check(lib.glf_s16_cast(_p(dy), DT_F32, _p(dx), DT_BF16, dy.numel(), _stream()), "s16_cast")
+        return dx
+
+
+class ToBF16Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_o._chk(x, "cast input"))
+        y = torch.empty(x.shape, dtype=BF, device=x.device)
+        check(lib.glf_s16_cast(_p(x), DT_F32, _p(y), DT_BF16, x.numel(), _stream()), "s16_cast")
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _contig(dy)
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        check(lib.glf_s16_cast(_p(dy), DT_BF16, _p(dx), DT_F32, dy.numel(), _stream()), "s16_cast")
+        return dx
+
+
+def to_f32(x):
+    return ToF32Fn.apply(x)
+
+
+def to_bf16(x):
+    return ToBF16Fn.apply(x)
+
+
+def colsum16(dy2d: torch.Tensor, rows: int, c: int, ld: Optional[int] = None) -> torch.Tensor:
+    db = torch.empty(c, dtype=torch.float32, device=dy2d.device)
+    ws = torch.empty(2 * c, dtype=torch.float64, device=dy2d.device)
+    check(lib.glf_s16_colsum(_p(dy2d), ld if ld is not None else c, _p(db), rows, c, _p(ws), _stream()), "s16_colsum")
+    return db
+
+
+# ----------------------------------------------------------------------------------------
+# conv2d
+# ----------------------------------------------------------------------------------------
+def _region(taps, kh, stride, pad, dil, h, w, ho, wo, mask, gather) -> int:
+    """rect = 2 (region mode) for 3x3 stride-1 "same" convs most of whose tap work is padding (ASPP rates 12 / 24)."""
+    if taps != 9 or kh != 3 or stride != 1 or pad != dil or h != ho or w != wo or bin(mask).count("1") <= 1:
+        return 0
+    frac = _o.rect_fraction(gather, ho, wo, h, w, 3, 3, pad, dil, mask) if gather == 1 else _o.rect_fraction(2, h, w, ho, wo, 3, 3, pad, dil, mask)
+    return 2 if frac < 0.8 else 0
+
+
+class Conv2d16Fn(Function):
+    """F.conv2d on bf16 [N,H,W,Cin] with the fp32 torch-layout weight [Cout,Cin,kh,kw] (groups = 1); bf16 result."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int, colstats=None):
+        _chk16(x, "conv input"); _o._chk(weight, "conv weight")
+        x = _contig(x)
+        n, h, w, cin = x.shape
+        cout, cin_w, kh, kw = weight.shape
+        if cin_w != cin:
+            raise RuntimeError(f"conv2d: input has {cin} channels, weight expects {cin_w}")
+        ho, wo = _o._conv_out(h, kh, stride, pad, dil), _o._conv_out(w, kw, stride, pad, dil)
+        if ho <= 0 or wo <= 0:
+            raise RuntimeError("conv2d: empty output")
+        taps = kh * kw
+        wt = weight16(_o.tap_major(weight), weight, "w")
+        y = torch.empty(n, ho, wo, cout, dtype=BF, device=x.device)
+        plain = taps == 1 and stride == 1 and pad == 0
+        geo = (n, h, w, ho, wo, kh, kw, stride, pad, dil)
+        mask = 1 if plain else _o.tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+        rect = 0 if plain else _region(taps, kh, stride, pad, dil, h, w, ho, wo, mask, 1)
+        gemm16("nt", x, wt, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias, taps=taps, mask=mask,
+               tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect, colstats=colstats)
+        ctx.save_for_backward(x)
+        ctx.weight_ref = weight
+        ctx.cfg = (n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, cin, cout, kh, kw, ho, wo, stride, pad, dil, plain, has_bias, wshape = ctx.cfg
+        weight = ctx.weight_ref
+        dy = _contig(dy)
+        taps = kh * kw
+        rows_o = n * ho * wo
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            mask = 1 if plain else _o.tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
+            if mask == 0:
+                dx = _o.zeros(x.shape, dtype=BF, device=x.device)
+            else:
+                rect = 0 if plain else _region(taps, kh, stride, pad, dil, h, w, ho, wo, mask, 2)
+                dx = torch.empty_like(x)
+                wT = weight16(_o.tap_major_T(weight), weight, "wT")
+                gemm16("nt", dy, wT, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin, taps=taps, mask=mask,
+                       tap_stride_b=cout * cin, gather=0 if plain else 2, geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
+        if ctx.needs_input_grad[1]:
+            mask = 1 if plain else _o.tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
+            ntap = bin(mask).count("1")
+            split = tn_split16(rows_o, cout, cin, ntap)
+            full = mask == (1 << taps) - 1
+            if taps == 1 and full:
+                dwt = _o.grad_out(weight, (1, cout, cin), x.device)
+            else:
+                dwt = (torch.empty if full else _o.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
+            gemm16("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask, tap_stride_b=cout * cin,
+                   gather=0 if plain else 1, geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split)
+            if taps == 1:
+                dw = dwt.view(wshape)
+            else:
+                dw = _o.grad_out(weight, wshape, x.device)
+                check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum16(dy, rows_o, cout)
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride: int = 1, pad: int = 0, dil: int = 1, colstats=None):
+    cout, cin = weight.shape[0], weight.shape[1]
+    if not s16_conv_ok(cin, cout):
+        # narrow outputs (the 5- / 1-channel head logits): through the exact fp32 kernels, result stays fp32
+        if colstats is not None:
+            raise RuntimeError("glfusion_amd: fused statistics need a convolution that runs on the 16-bit kernels")
+        return _o.Conv2dFn.apply(to_f32(x), weight, bias, stride, pad, dil, None)
+    return Conv2d16Fn.apply(x, weight, bias, stride, pad, dil, colstats)
+
+
+class ConvCat16Fn(Function):
+    """1x1 conv over the channel concatenation of inputs that ARE the column slices of one [..., ctot] bf16 buffer (ASPP project,
+    deeplabv3.py:153-165): one K = ctot contraction."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, colstats, *xs):
+        _o._chk(weight, "weight")
+        cout, ctot = weight.shape[0], weight.shape[1]
+        t0 = _chk16(xs[0], "input")
+        offs = [0]
+        for t in xs:
+            offs.append(offs[-1] + t.shape[-1])
+        cat = (offs[-1] == ctot and t0.stride(-1) == 1 and t0.stride(-2) == ctot
+               and all(_chk16(t, "input").stride() == t0.stride() and t.shape[:-1] == t0.shape[:-1]
+                       and t.data_ptr() == t0.data_ptr() + 2 * o for t, o in zip(xs, offs)))
+        if not cat:
+            raise RuntimeError("glfusion_amd: 16-bit conv1x1_cat needs its inputs to be the column slices of one buffer")
+        rows = t0.numel() // t0.shape[-1]
+        w2 = _contig(weight.detach()).view(cout, ctot)
+        y = torch.empty(*t0.shape[:-1], cout, dtype=BF, device=t0.device)
+        gemm16("nt", t0, weight16(w2, weight, "w"), y, M=rows, N=cout, K=ctot, lda=ctot, ldb=ctot, ldc=cout, bias=bias, colstats=colstats)
+        ctx.save_for_backward(*xs)
+        ctx.weight_ref = weight
+        ctx.cfg = (rows, cout, ctot, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xs = ctx.saved_tensors
+        rows, cout, ctot, has_bias, wshape = ctx.cfg
+        weight = ctx.weight_ref
+        dy = _contig(dy)
+        t0 = xs[0]
+        dw = db = None
+        grads = [None] * len(xs)
+        w2 = _contig(weight.detach()).view(cout, ctot)
+        if any(ctx.needs_input_grad[3:]):
+            dcat = torch.empty(*t0.shape[:-1], ctot, dtype=BF, device=dy.device)
+            gemm16("nt", dy, weight16(_o.weight_T(w2, weight), weight, "T2"), dcat, M=rows, N=ctot, K=cout, lda=cout, ldb=cout, ldc=ctot)
+            off = 0
+            grads = []
+            for t in xs:
+                grads.append(dcat[..., off:off + t.shape[-1]])
+                off += t.shape[-1]
+        if ctx.needs_input_grad[0]:
+            dw = _o.grad_out(weight, (cout, ctot), dy.device)
+            gemm16("tn", dy, t0, dw, M=cout, N=ctot, K=rows, lda=cout, ldb=ctot, ldc=ctot, split=tn_split16(rows, cout, ctot, 1))
+            dw = dw.view(wshape)
+        if has_bias and ctx.needs_input_grad[1]:
+            db = colsum16(dy, rows, cout)
+        return (dw, db, None, *grads)
+
+
+def conv1x1_cat(weight, xs: Sequence[torch.Tensor], bias=None, colstats=None):
+    return ConvCat16Fn.apply(weight, bias, colstats, *xs)
+
+
+# ----------------------------------------------------------------------------------------
+# stem
+# ----------------------------------------------------------------------------------------
+class Stem16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad: int):
+        _o._chk(x, "stem input"); _o._chk(weight, "stem weight")
+        x = _contig(x)
+        n, h, w, _ = x.shape
+        cout = weight.shape[0]
+        y = torch.empty(n, h + 2 * pad - 6, w + 2 * pad - 6, cout, dtype=BF, device=x.device)
+        check(lib.glf_s16_stem7x7_fwd(_p(x), _p(_contig(weight.detach())), _p(bias), _p(y), n, h, w, cout, pad, _stream()), "s16_stem7x7_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (n, h, w, cout, pad, tuple(weight.shape), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, cout, pad, wshape, has_bias = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("glfusion_amd: gradient w.r.t. the input image is not on the path (stem dgrad not built)")
+        dy = _contig(dy)
+        dw = torch.empty(wshape, dtype=torch.float32, device=dy.device)
+        db = torch.empty(cout, dtype=torch.float32, device=dy.device) if has_bias else None
+        part = torch.empty(int(lib.glf_stem7x7_wgrad_workspace(n, h, w, cout, pad)), dtype=torch.float32, device=dy.device)
+        check(lib.glf_s16_stem7x7_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(part), n, h, w, cout, pad, _stream()), "s16_stem7x7_wgrad")
+        return None, dw, db, None
+
+
+def stem7x7(x, weight, bias, pad: int):
+    return Stem16Fn.apply(x, weight, bias, pad)
+
+
+# ----------------------------------------------------------------------------------------
+# BatchNorm (+ residual, + ReLU)
+# ----------------------------------------------------------------------------------------
+def _take_out16(shape, device):
+    """(output tensor, row stride): the pending ops.output_into view when it matches, a fresh bf16 tensor otherwise."""
+    item = _o._OUT_VIEW[0]
+    if item is not None and tuple(item[0].shape) == tuple(shape) and item[0].stride(-1) == 1 and item[0].dtype == BF:
+        _o._OUT_VIEW[0] = None
+        return item[0], int(item[0].stride(-2))
+    return torch.empty(tuple(shape), dtype=BF, device=device), int(shape[-1])
+
+
+def _rows_view16(t: torch.Tensor):
+    if t.is_contiguous():
+        return t, int(t.shape[-1])
+    if t.dim() >= 2 and t.stride(-1) == 1:
+        ld = int(t.stride(-2))
+        ok = all(t.stride(d) == t.stride(d + 1) * t.shape[d + 1] for d in range(t.dim() - 2))
+        if ok and ld >= t.shape[-1] and ld % 8 == 0 and t.data_ptr() % 16 == 0:
+            return t, ld
+    t = t.contiguous()
+    return t, int(t.shape[-1])
+
+
+class BatchNormAct16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training: bool, momentum: float, eps: float, relu: bool, sums=None):
+        _chk16(x, "bn input"); _o._chk(gamma, "bn weight"); _o._chk(beta, "bn bias")
+        x = _contig(x)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dev = x.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty(c, dtype=torch.float32, device=dev)
+        if training:
+            if sums is None:                     # no producing contraction left them: one pass over x
+                sums = _o.stats_slot(c, dev)
+                check(lib.glf_s16_colstats(_p(x), c, rows, c, _p(sums), _stream()), "s16_colstats")
+        else:
+            if running_mean is None or running_var is None:
+                raise RuntimeError("batch_norm in eval mode needs running statistics")
+            check(lib.glf_bn_eval_coeffs(_p(running_mean), _p(running_var), eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
+            sums = None
+        if residual is not None:
+            residual = _contig(_chk16(residual, "bn residual"))
+        y, ldy = _take_out16(x.shape, dev)
+        # (grad mode is always off inside Function.forward: what says that a backward may follow is needs_input_grad)
+        need_mask = relu and residual is not None and any(ctx.needs_input_grad[:4])
+        mask = torch.empty(rows * (c // 8), dtype=torch.uint8, device=dev) if need_mask else None
+        check(lib.glf_s16_bn_apply(_p(x), c, _p(residual), c, _p(y), ldy, _p(sums), rows, c, eps, momentum, _p(gamma), _p(beta), _p(mean), _p(invstd),
+                                   _p(running_mean) if training else None, _p(running_var) if training else None, _p(nbt) if training else None,
+                                   int(relu), _p(mask), _stream()), "s16_bn_apply")
+        ctx.save_for_backward(x, mask, mean, invstd, gamma, beta if relu else None)
+        ctx.cfg = (rows, c, relu, training, residual is not None)
+        ctx.param_refs = (gamma, beta)
+        _o._last_bn[0] = (mean, invstd, rows)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mask, mean, invstd, gamma, beta = ctx.saved_tensors
+        rows, c, relu, training, has_res = ctx.cfg
+        dy2 = getattr(dy, "_glf_addend", None)
+        lddy2 = 0
+        dy, lddy = _rows_view16(dy)
+        if dy2 is not None:
+            if dy2.shape != dy.shape:
+                raise RuntimeError("glfusion_amd: the two addends of a lazy fan-in gradient differ in shape")
+            dy2, lddy2 = _rows_view16(dy2)
+        dev = dy.device
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
+        dgamma = _o.grad_out(ctx.param_refs[0], (c,), dev)
+        dbeta = _o.grad_out(ctx.param_refs[1], (c,), dev)
+        sums = _o.stats_slot(c, dev)
+        check(lib.glf_s16_bn_bwd(_p(dy), lddy, _p(dy2), lddy2, _p(x), c, _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dx), c, _p(dres), c,
+                                 _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(sums), _p(mask), _stream()), "s16_bn_bwd")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
+# pooling / dropout / broadcast / relu / fan-in
+# ----------------------------------------------------------------------------------------
+class MaxPool16Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk16(x, "maxpool input"))
+        n, h, w, c = x.shape
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        y = torch.empty(n, ho, wo, c, dtype=BF, device=x.device)
+        idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=x.device)
+        check(lib.glf_s16_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()), "s16_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.cfg = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(n, h, w, c, dtype=BF, device=dy.device)
+        check(lib.glf_s16_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _stream()), "s16_maxpool_bwd")
+        return dx
+
+
+class AvgPool16Fn(Function):
+    """AdaptiveAvgPool2d(1) on a bf16 map -> fp32 [N,1,1,C]: the ASPP pooled branch (deeplabv3.py:123-135) stays fp32 up to its
+    broadcast -- its BatchNorm normalises over the N per-frame averages, which differ by less than a few bf16 steps."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk16(x, "avgpool input"))
+        n, h, w, c = x.shape
+        y = torch.empty(n, 1, 1, c, dtype=torch.float32, device=x.device)
+        check(lib.glf_s16_sum_rows(_p(x), c, _p(y), DT_F32, 1.0 / (h * w), n, h * w, c, _stream()), "s16_avgpool_fwd")
+        ctx.cfg = (n, h, w, c)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty(n, h, w, c, dtype=BF, device=dy.device)
+        check(lib.glf_s16_bcast_rows(_p(dy), DT_F32, _p(dx), c, 1.0 / (h * w), n, h * w, c, _stream()), "s16_avgpool_bwd")
+        return dx
+
+
+class Broadcast16Fn(Function):
+    """bilinear up-sampling from a 1x1 map == broadcast: fp32 or bf16 [N,1,1,C] -> bf16 [N,H,W,C] (into the pending output view)."""
+
+    @staticmethod
+    def forward(ctx, x, h: int, w: int):
+        x = _contig(x)
+        if not x.is_cuda or x.dtype not in (BF, torch.float32):
+            raise RuntimeError("glfusion_amd: broadcast input must be a CUDA fp32 / bf16 tensor")
+        n, c = x.shape[0], x.shape[-1]
+        y, ldy = _take_out16((n, h, w, c), x.device)
+        check(lib.glf_s16_bcast_rows(_p(x), DT_BF16 if x.dtype == BF else DT_F32, _p(y), ldy, 1.0, n, h * w, c, _stream()), "s16_bcast_rows")
+        ctx.cfg = (n, h, w, c, x.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c, xdt = ctx.cfg
+        dy, lddy = _rows_view16(dy)
+        dx = torch.empty(n, 1, 1, c, dtype=xdt, device=dy.device)
+        check(lib.glf_s16_sum_rows(_p(dy), lddy, _p(dx), DT_BF16 if xdt == BF else DT_F32, 1.0, n, h * w, c, _stream()), "s16_bcast_rows_bwd")
+        return dx, None, None
+
+
+class Dropout16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int):
+        x = _contig(_chk16(x, "dropout input"))
+        y = torch.empty_like(x)
+        check(lib.glf_s16_dropout(_p(x), _p(y), x.numel(), p, seed, _p(_o.step_counter(x.device)), _stream()), "s16_dropout")
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        dy = _contig(dy)
+        dx = torch.empty_like(dy)
+        check(lib.glf_s16_dropout(_p(dy), _p(dx), dy.numel(), p, seed, _p(_o.step_counter(dy.device)), _stream()), "s16_dropout_bwd")
+        return dx, None, None
+
+
+class Relu16Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(_chk16(x, "relu input"))
+        y = torch.empty_like(x)
+        check(lib.glf_s16_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "s16_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _contig(dy)
+        dx = torch.empty_like(dy)
+        check(lib.glf_s16_relu_bwd(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "s16_relu_bwd")
+        return dx
+
+
+class Axpby16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, y, a: float, b: float):
+        x, y = _contig(_chk16(x, "x")), _contig(_chk16(y, "y"))
+        if x.shape != y.shape:
+            raise RuntimeError("axpby: shapes differ")
+        out = torch.empty_like(x)
+        check(lib.glf_s16_axpby(_p(x), _p(y), _p(out), a, b, x.numel(), _stream()), "s16_axpby")
+        ctx.ab = (a, b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        a, b = ctx.ab
+        d = _contig(d)
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(d)
+            check(lib.glf_s16_axpby(_p(d), _p(d), _p(dx), a, 0.0, d.numel(), _stream()), "s16_axpby_bwd")
+        if ctx.needs_input_grad[1]:
+            dy = torch.empty_like(d)
+            check(lib.glf_s16_axpby(_p(d), _p(d), _p(dy), b, 0.0, d.numel(), _stream()), "s16_axpby_bwd")
+        return dx, dy, None, None
+
+
+def add_n16(live) -> torch.Tensor:
+    out = torch.empty_like(live[0])
+    n = out.numel()
+    if n % 8 != 0 or any(d.shape != out.shape for d in live) or len(live) > 8:
+        raise RuntimeError("fan_out: gradients must share one shape with numel % 8 == 0 (<= 8 branches)")
+    arr = (C.c_void_p * len(live))(*[d.data_ptr() for d in live])
+    check(lib.glf_s16_add_n(arr, len(live), _p(out), n, _stream()), "s16_add_n")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# local gate, view stacking
+# ----------------------------------------------------------------------------------------
+class Gate16Fn(Function):
+    @staticmethod
+    def forward(ctx, cls, ctr, f, weight: float):
+        cls, ctr, f = _contig(_o._chk(cls, "cls")), _contig(_o._chk(ctr, "ctr")), _contig(_chk16(f, "f4"))
+        c = f.shape[-1]
+        rows = f.numel() // c
+        ncls = cls.shape[-1]
+        y = torch.empty_like(f)
+        a = torch.empty(rows, dtype=torch.float32, device=f.device)
+        am = torch.empty(rows, dtype=torch.int32, device=f.device)
+        check(lib.glf_s16_gate_fwd(_p(cls), ncls, _p(ctr), _p(f), _p(y), _p(a), _p(am), weight, rows, c, _stream()), "s16_gate_fwd")
+        ctx.save_for_backward(cls, ctr, f, a, am)
+        ctx.cfg = (rows, c, ncls, weight)
+        ctx.mark_non_differentiable(a)
+        return y, a
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _da):
+        cls, ctr, f, a, am = ctx.saved_tensors
+        rows, c, ncls, weight = ctx.cfg
+        dy = _contig(dy)
+        df = torch.empty_like(f)
+        dcls = torch.empty_like(cls)
+        dctr = torch.empty_like(ctr)
+        check(lib.glf_s16_gate_bwd(_p(dy), _p(f), _p(cls), ncls, _p(ctr), _p(a), _p(am), weight, _p(df), _p(dcls), _p(dctr), rows, c, _stream()),
+              "s16_gate_bwd")
+        return dcls, dctr, df, None
+
+
+def _copy_frames16(src, sfs, dst, dfs, n, inner):
+    """glf_copy_frames moves 16-byte pieces: counted in floats, a bf16 extent is half as long."""
+    check(lib.glf_copy_frames(_p(src), sfs // 2, _p(dst), dfs // 2, n, inner // 2, _stream()), "copy_frames(s16)")
+
+
+class StackViews16Fn(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_contig(_chk16(t, "view feature")) for t in xs]
+        n, h, w, c = xs[0].shape
+        v = len(xs)
+        out = torch.empty(n, v, h, w, c, dtype=BF, device=xs[0].device)
+        inner = h * w * c
+        for i, t in enumerate(xs):
+            _copy_frames16(t, inner, out[:, i], v * inner, n, inner)
+        ctx.cfg = (n, v, h, w, c)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, v, h, w, c = ctx.cfg
+        dy = _contig(dy)
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            g = torch.empty(n, h, w, c, dtype=BF, device=dy.device)
+            _copy_frames16(dy[:, i], v * inner, g, inner, n, inner)
+            outs.append(g)
+        return tuple(outs)
+
+
+class AddViews16Fn(Function):
+    @staticmethod
+    def forward(ctx, g, l):
+        g, l = _contig(_chk16(g, "global")), _contig(_chk16(l, "local"))
+        n, v, h, w, c = g.shape
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            out = torch.empty(n, h, w, c, dtype=BF, device=g.device)
+            check(lib.glf_s16_add_frames(_p(g[:, i]), v * inner, _p(l[:, i]), v * inner, _p(out), inner, n, inner, _stream()), "s16_add_views")
+            outs.append(out)
+        ctx.cfg = (n, v, h, w, c)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        n, v, h, w, c = ctx.cfg
+        inner = h * w * c
+        dev = next(d.device for d in dys if d is not None)
+        dg = (_o.zeros if any(d is None for d in dys) else torch.empty)(n, v, h, w, c, dtype=BF, device=dev)
+        for i, d in enumerate(dys):
+            if d is not None:
+                _copy_frames16(_contig(d), inner, dg[:, i], v * inner, n, inner)
+        return dg, dg
+
+
+class SplitViews16Fn(Function):
+    @staticmethod
+    def forward(ctx, g):
+        g = _contig(_chk16(g, "stacked views"))
+        n, v, h, w, c = g.shape
+        inner = h * w * c
+        outs = []
+        for i in range(v):
+            out = torch.empty(n, h, w, c, dtype=BF, device=g.device)
+            _copy_frames16(g[:, i], v * inner, out, inner, n, inner)
+            outs.append(out)
+        ctx.cfg = (n, v, h, w, c)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        n, v, h, w, c = ctx.cfg
+        inner = h * w * c
+        dev = next(d.device for d in dys if d is not None)
+        dg = (_o.zeros if any(d is None for d in dys) else torch.empty)(n, v, h, w, c, dtype=BF, device=dev)
+        for i, d in enumerate(dys):
+            if d is not None:
+                _copy_frames16(_contig(d), inner, dg[:, i], v * inner, n, inner)
+        return dg
+
+
+def transpose16(x: torch.Tensor, rows: int, cols: int, batch: int = 1) -> torch.Tensor:
+    out = torch.empty(batch * rows * cols, dtype=BF, device=x.device)
+    check(lib.glf_s16_transpose2d(_p(x), _p(out), rows, cols, batch, _stream()), "s16_transpose2d")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# the fusion block (TPAVIModule.forward, ours.py:845-917), dot mode
+# ----------------------------------------------------------------------------------------
+class Tpavi16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, th_w, th_b, ph_w, ph_b, g_w, g_b, wz_w, wz_b, bn_g, bn_b, ln_g, ln_b, rmean, rvar, nbt, training: bool,
+                momentum: float, bn_eps: float, ln_eps: float, mode: str):
+        from .fusion import _qkv_weights
+        x = _contig(_chk16(x, "TPAVI input"))
+        if x.dim() != 5:
+            raise RuntimeError("TPAVI input must be [N, V, h, w, C]")
+        if mode != "dot":
+            raise RuntimeError("glfusion_amd: 16-bit storage builds TPAVI mode 'dot' (the shipped model); 'embedded' runs under the fp32-storage precisions")
+        n, v, h, w_, c = x.shape
+        L = v * h * w_
+        rows = n * L
+        ci = th_w.shape[0]
+        if c % 64 != 0 or ci % 64 != 0:
+            raise RuntimeError("glfusion_amd: 16-bit TPAVI needs channel counts that are multiples of 64")
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        zW = _contig(wz_w.detach()).view(wz_w.shape[0], wz_w.shape[1])
+        Wcat, bcat = _qkv_weights((th_w, ph_w, g_w, th_b, ph_b, g_b))
+        c3 = 3 * ci
+        qkv = torch.empty(rows, c3, dtype=BF, device=dev)
+        gemm16("nt", x, weight16(Wcat, Wcat, "w"), qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat)
+        th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
+        bq = L * c3
+        # M_n^T[a][b] = sum_r g[r][a] phi[r][b] / L  (TN with A = g, B = phi): the B operand of y_n = theta_n M_n as it stands
+        attT = torch.empty(n, ci, ci, dtype=BF, device=dev)
+        gemm16("tn", g, ph, attT, M=ci, N=ci, K=L, lda=c3, ldb=c3, ldc=ci, batch=n, bsa=bq, bsb=bq, bsc=ci * ci, alpha=1.0 / L)
+        y = torch.empty(rows, ci, dtype=BF, device=dev)
+        gemm16("nt", th, attT, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
+        wz = torch.empty(rows, c, dtype=BF, device=dev)
+        sums = _o.stats_slot(c, dev) if training else None
+        gemm16("nt", y, weight16(zW, wz_w, "w"), wz, M=rows, N=c, K=ci, lda=ci, ldb=ci, ldc=c, bias=wz_b, colstats=sums)
+        mean = torch.empty(c, **f32)
+        invstd = torch.empty(c, **f32)
+        if training:
+            check(lib.glf_bn_stats_from_sums(_p(sums), rows, c, bn_eps, momentum, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt), _stream()),
+                  "bn_stats_from_sums")
+        else:
+            check(lib.glf_bn_eval_coeffs(_p(rmean), _p(rvar), bn_eps, _p(mean), _p(invstd), c, _stream()), "bn_eval_coeffs")
+        z = torch.empty_like(x)
+        rmu = torch.empty(rows, **f32)
+        rrs = torch.empty(rows, **f32)
+        check(lib.glf_s16_bn_res_ln_fwd(_p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(ln_b), ln_eps, _p(z), _p(rmu), _p(rrs),
+                                        rows, c, _stream()), "s16_bn_res_ln_fwd")
+        ctx.save_for_backward(x, qkv, attT, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g)
+        ctx.cfg = (n, L, c, ci, training, tuple(th_w.shape), tuple(wz_w.shape))
+        ctx.owners = (wz_w,)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        (x, qkv, attT, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g) = ctx.saved_tensors
+        n, L, c, ci, training, pshape, zshape = ctx.cfg
+        (wz_o,) = ctx.owners
+        rows = n * L
+        dev = dz.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dz = _contig(dz)
+        c3 = 3 * ci
+        bq, bs = L * c3, L * ci
+        th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
+        du = torch.empty(rows, c, dtype=BF, device=dev)
+        dln_g = torch.empty(c, **f32)
+        dln_b = torch.empty(c, **f32)
+        ws = torch.empty(int(lib.glf_s16_bn_res_ln_workspace(rows, c)) // 4, **f32)
+        check(lib.glf_s16_bn_res_ln_bwd(_p(dz), _p(wz), _p(x), _p(mean), _p(invstd), _p(bn_g), _p(bn_b), _p(ln_g), _p(rmu), _p(rrs), _p(du), _p(dln_g),
+                                        _p(dln_b), rows, c, _p(ws), _stream()), "s16_bn_res_ln_bwd")
+        dwz = torch.empty(rows, c, dtype=BF, device=dev)
+        dbn_g = torch.empty(c, **f32)
+        dbn_b = torch.empty(c, **f32)
+        check(lib.glf_s16_bn_bwd(_p(du), c, None, 0, _p(wz), c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, 0, _p(dbn_g), _p(dbn_b),
+                                 rows, c, 0, int(training), _p(_o.stats_slot(c, dev)), None, _stream()), "s16_bn_bwd")
+        dzW = torch.empty(c, ci, **f32)
+        gemm16("tn", dwz, y, dzW, M=c, N=ci, K=rows, lda=c, ldb=ci, ldc=ci, split=tn_split16(rows, c, ci, 1))
+        # train mode: the bias feeds a BatchNorm, its gradient is zero in exact arithmetic (fusion.TpaviFn.backward)
+        dzb = _o.zeros(c, device=dev) if training else colsum16(dwz, rows, c)
+        dy = torch.empty(rows, ci, dtype=BF, device=dev)
+        gemm16("nt", dwz, weight16(_o.weight_T(zW, wz_o), wz_o, "T2"), dy, M=rows, N=ci, K=c, lda=c, ldb=c, ldc=ci)
+        del dwz
+        dqkv = torch.empty(rows, c3, dtype=BF, device=dev)
+        dth, dph, dg = dqkv[:, 0:ci], dqkv[:, ci:2 * ci], dqkv[:, 2 * ci:]
+        att = transpose16(attT, ci, ci, n)                     # M_n
+        gemm16("nt", dy, att, dth, M=L, N=ci, K=ci, lda=ci, ldb=ci, ldc=c3, batch=n, bsa=bs, bsb=ci * ci, bsc=bq)
+        dM = torch.empty(n, ci, ci, dtype=BF, device=dev)      # dM_n = theta_n^T dy_n
+        gemm16("tn", th, dy, dM, M=ci, N=ci, K=L, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=bs, bsc=ci * ci)
+        gemm16("nt", g, dM, dph, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+        dMT = transpose16(dM, ci, ci, n)
+        gemm16("nt", ph, dMT, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+        del dy, att, dM, dMT
+        dWcat = torch.empty(c3, c, **f32)
+        gemm16("tn", dqkv, x, dWcat, M=c3, N=c, K=rows, lda=c3, ldb=c, ldc=c, split=tn_split16(rows, c3, c, 1))
+        dbcat = colsum16(dqkv, rows, c3)
+        grads_w = [dWcat[i * ci:(i + 1) * ci].reshape(pshape) for i in range(3)]
+        grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
+        dx = du                                                # the residual's gradient; the projections' dgrad adds onto it
+        gemm16("nt", dqkv, weight16(_o.weight_T(Wcat, Wcat), Wcat, "T2"), dx, M=rows, N=c, K=c3, lda=c3, ldb=c3, ldc=c, accumulate=True)
+        return (dx.view_as(x), grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], dzW.view(zshape), dzb,
+                dbn_g, dbn_b, dln_g, dln_b, None, None, None, None, None, None, None, None)

@@ -294,6 +294,8 @@ enum {
                                scaled by *amax, as glf_split_f16_packed                          (pass 3) */
     GLF_WJ_ZERO = 6,        /* dst[i] = 0, d0 elements (src unused): the amax slots of a table that covers only SOME of an
                                arena's parameters -- such a caller passes amax_arena = NULL to glf_weights_refresh      (pass 0) */
+    GLF_WJ_CVT_BF16 = 7,    /* dst (bf16 elements behind the float* field) = round-to-nearest-even(src), d0 elements (% 4 == 0): the operand
+                               images of the 16-bit-storage contractions, from fp32 master weights or their layouts   (pass 3) */
     GLF_WJ_PASSES = 4
 };
 typedef struct {
@@ -313,6 +315,69 @@ int glf_weights_plan(glf_weight_job* jobs_host, int n_jobs, int* pass_first, int
  * to device memory (jobs_dev), in order, on `s`. */
 int glf_weights_refresh(const glf_weight_job* jobs_dev, const int* pass_first, const int* pass_count, const int64_t* pass_wgs,
                         float* amax_arena, int64_t amax_floats, glf_stream_t s);
+
+/* ---------------------------------------------------------------------------------------
+ * 16-bit storage ("S16"), streaming kernels: the counterparts of the normalisation / pointwise
+ * entry points above for bf16 tensors (`void*` = bf16 elements unless named float; channel
+ * counts and row strides multiples of 8, 16-byte aligned tensors).  fp32 arithmetic, one
+ * rounding at the store.  BatchNorm sums follow the glf_gemm_params.colstats contract: DEVICE
+ * doubles [2][C], zero-filled by the caller, filled by glf_s16_gemm_nt's epilogue or by
+ * glf_s16_colstats; the apply kernels finish the statistics themselves.
+ * ------------------------------------------------------------------------------------- */
+/* sums[c] += sum_r x[r][c]; sums[C + c] += sum_r x[r][c]^2 (f64 atomics, one per column and workgroup). */
+int glf_s16_colstats(const void* x, int ldx, int rows, int c, double* sums, glf_stream_t s);
+/* y = [relu]( BN(x) [+ residual] ).  sums != NULL (train): batch statistics from sums, written to mean / invstd, running
+ * statistics updated (as glf_bn_apply_from_sums).  sums == NULL (eval): mean / invstd are inputs (glf_bn_eval_coeffs).
+ * relu_mask (may be NULL): one byte per 8 channels, bit j = sign of the pre-ReLU value of channel 8 i + j. */
+int glf_s16_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* y, int ldy, const double* sums,
+                     int rows, int c, float eps, float momentum, const float* gamma, const float* beta,
+                     float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     int relu, uint8_t* relu_mask, glf_stream_t s);
+/* BatchNorm backward in two launches: column reduction (sum dy', sum dy' xhat; into `sums`, DEVICE doubles [2][C] zero-filled
+ * by the caller) and apply (finishes the sums, writes dgamma / dbeta / dx / dres).  dy2 (may be NULL): second addend of the
+ * incoming gradient; relu: relu_mask (bytes of glf_s16_bn_apply) or, without a residual, recomputed from x and beta. */
+int glf_s16_bn_bwd(const void* dy, int lddy, const void* dy2, int lddy2, const void* x, int ldx,
+                   const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                   int rows, int c, int relu, int training, double* sums, const uint8_t* relu_mask, glf_stream_t s);
+/* db[c] = sum_r dy[r][c]; workspace: 2 C doubles (zero-filled by the call). */
+int glf_s16_colsum(const void* dy, int lddy, float* db, int rows, int c, double* workspace, glf_stream_t s);
+/* TPAVI tail (ours.py:908-915) on bf16 w, x, z, dz, du; statistics vectors fp32. */
+int glf_s16_bn_res_ln_fwd(const void* w, const void* x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                          const float* bn_beta, const float* ln_gamma, const float* ln_beta, float ln_eps, void* z,
+                          float* row_mean, float* row_rstd, int rows, int c, glf_stream_t s);
+size_t glf_s16_bn_res_ln_workspace(int rows, int c);   /* bytes */
+int glf_s16_bn_res_ln_bwd(const void* dz, const void* w, const void* x, const float* bn_mean, const float* bn_invstd,
+                          const float* bn_gamma, const float* bn_beta, const float* ln_gamma, const float* row_mean,
+                          const float* row_rstd, void* du, float* dln_gamma, float* dln_beta, int rows, int c,
+                          float* workspace, glf_stream_t s);
+/* Stem with a bf16 conv output / output gradient (x, w, bias, dw, db fp32). */
+int glf_s16_stem7x7_fwd(const float* x, const float* w, const float* bias, void* y,
+                        int n, int h, int wdt, int cout, int pad, glf_stream_t s);
+int glf_s16_stem7x7_wgrad(const float* x, const void* dy, float* dw, float* db, float* partial,
+                          int n, int h, int wdt, int cout, int pad, glf_stream_t s);
+int glf_s16_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int n, int h, int w, int c, glf_stream_t s);
+int glf_s16_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int n, int h, int w, int c, glf_stream_t s);
+/* y[n][c] = scale * sum_p x[n][p][c] (x bf16, row stride ldx; y of y_dtype); y[n][p][c] (bf16, row stride ldy) = scale * x[n][c]
+ * (x of x_dtype).  The ASPP pooled branch (deeplabv3.py:123-135) keeps its N per-frame vectors in fp32. */
+int glf_s16_sum_rows(const void* x, int ldx, void* y, int y_dtype, float scale, int n, int p, int c, glf_stream_t s);
+int glf_s16_bcast_rows(const void* x, int x_dtype, void* y, int ldy, float scale, int n, int p, int c, glf_stream_t s);
+int glf_s16_dropout(const void* x, void* y, int64_t numel, float p, uint64_t seed, const uint64_t* step_counter, glf_stream_t s);
+int glf_s16_relu_fwd(const void* x, void* y, int64_t numel, glf_stream_t s);
+int glf_s16_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, glf_stream_t s);
+int glf_s16_axpby(const void* x, const void* y, void* out, float a, float b, int64_t numel, glf_stream_t s);
+/* Local gate (ours.py:1802-1816): cls / ctr logits, gate map, their gradients fp32; f, y, dy, df bf16. */
+int glf_s16_gate_fwd(const float* cls, int ncls, const float* ctr, const void* f, void* y, float* a, int32_t* argmax, float weight,
+                     int rows, int c, glf_stream_t s);
+int glf_s16_gate_bwd(const void* dy, const void* f, const float* cls, int ncls, const float* ctr, const float* a, const int32_t* argmax,
+                     float weight, void* df, float* dcls, float* dctr, int rows, int c, glf_stream_t s);
+int glf_s16_add_frames(const void* a, int64_t a_fs, const void* b, int64_t b_fs, void* dst, int64_t dst_fs, int n, int64_t inner,
+                       glf_stream_t s);
+int glf_s16_add_n(const void* const* inputs, int k, void* out, int64_t numel, glf_stream_t s);
+/* dst (dst_dtype) = src (src_dtype): GLF_DT_BF16 -> GLF_DT_F32 or GLF_DT_F32 -> GLF_DT_BF16; numel % 8 == 0. */
+int glf_s16_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, glf_stream_t s);
+/* dst[b][c][r] = src[b][r][c] for 16-bit elements. */
+int glf_s16_transpose2d(const void* src, void* dst, int rows, int cols, int batch, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Stem (a2): Conv2d(1,64,7,stride 1,pad 2)+bias (models/_utils.py:192; used ours.py:1796).
