@@ -63,10 +63,16 @@ def pmc_traffic_per_launch(kernel: str, precision: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
     profiles/summarize_pmc.py) -- PMC counters cannot be collected inside this process, so the figure is the one
     measured on the same workload when the profile was taken; None if the profile is missing."""
-    for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_c2_{precision}_pmc_hbm_traffic.csv")
-        if os.path.exists(path):
-            break
+    path = os.path.join(ROOT, "profiles", f"r04_bench_c2_{precision}_pmc_hbm_traffic.csv")
+    # a profile is only as good as the kernels it was taken on: the CSV carries a stamp (git hash + a hash of the kernel sources)
+    # written when it was collected (profiles/ubench/r04_profiles.sh -> profiles/stamp.py); a stale or unstamped one is refused
+    try:
+        meta = json.load(open(path[:-4] + ".meta.json"))
+    except (OSError, ValueError):
+        return {"bytes_per_launch": None, "reason": f"no stamped profile {os.path.relpath(path, ROOT)}"}
+    if meta.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return {"bytes_per_launch": None, "reason": f"{os.path.relpath(path, ROOT)} was collected at {meta.get('git_hash', '?')[:12]} on different kernel "
+                                                    "sources (csrc/ changed since): re-profile"}
     try:
         launches, gb = 0, 0.0
         for line in open(path).read().splitlines()[1:]:
@@ -79,10 +85,23 @@ def pmc_traffic_per_launch(kernel: str, precision: str):
                 launches += int(rest[0])
                 gb += float(rest[3])
         if launches:
-            return {"bytes_per_launch": round(gb * 1e9 / launches), "unit": "B", "source": os.path.relpath(path, ROOT)}
+            return {"bytes_per_launch": round(gb * 1e9 / launches), "unit": "B", "source": os.path.relpath(path, ROOT),
+                    "collected_at": meta.get("git_hash"), "bench_sha256": meta.get("bench_sha256")}
     except (OSError, ValueError, IndexError):
         pass
-    return None
+    return {"bytes_per_launch": None, "reason": f"{os.path.relpath(path, ROOT)} has no row for {kernel}"}
+
+
+def kernel_sources_sha256() -> str:
+    """Hash of everything the kernels are built from (csrc/*.hip, *.h, the C header): what a profile-derived number depends on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gl-fusion_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gl-fusion_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "include", "glfusion.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def host_cores() -> int:
@@ -197,7 +216,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default since the eager step became the faster one) time the eagerly issued step")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short measurement of the launch mode that was not timed")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
-    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
+    ap.add_argument("--no-bf16", action="store_true", help="skip the 16-bit-storage leg (BASELINE.json configs[2] as stated: bf16 storage)")
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16", "bf16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
                          "passes the same parity gates), f16x3 = amax-scaled split-fp16 (three fp16 MFMAs per product, same gates; "
                          "default) or f32 = exact v_mfma_f32_32x32x2_f32")
@@ -290,6 +310,7 @@ def main():
         HIP event pair around every contraction launch (on side streams a launch's event interval would include the time
         it shared the chip with other streams' kernels)."""
         ops.set_precision(precision)
+        ops.reset_weight_images()                  # the previous leg's weight images are not this leg's per-update work
         if os.environ.get("GLF_BENCH_STEPTIMES", "0") != "0":       # diagnostic: every step fenced and timed (allocator / cache warm-up effects)
             for i in range(args.warmup + args.steps):
                 ts = time.perf_counter()
@@ -390,11 +411,13 @@ def main():
         all_secs = sum(a[0] for a in agg.values())
         all_dense = sum(a[1] for a in agg.values())
         all_kept = sum(a[2] for a in agg.values())
-        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3, "f16": 1}[precision]
+        nmul = {"f32": 1, "bf16x6": 6, "f16x3": 3, "f16": 1, "bf16": 1}[precision]
         # f32   : achieved = dense fp32 FLOPs of the dominant kernel / its time, against the fp32 MFMA peak
         # bf16x6: the kernel executes SIX bf16 MFMA FLOPs per (host-kept) algorithmic FLOP; achieved = those executed
         #         16-bit FLOPs / time against the dense 16-bit MFMA peak (f16x3: THREE fp16 MFMA FLOPs per algorithmic FLOP)
-        if precision != "f32":
+        if precision == "bf16":
+            achieved, peak, kname = kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS, name
+        elif precision != "f32":
             achieved, peak = nmul * kept / secs / 1e12, BF16_MFMA_PEAK_TFLOPS
             fam = "bf16s" if precision == "bf16x6" else "f16s"        # (f16 runs the f16s kernels with one product)
             kname = name.replace("gemm_rows_kernel<0,", f"gemm_rows_{fam}8_kernel<").replace("gemm_tn_kernel<", f"gemm_tn_{fam}8_kernel<")
@@ -408,7 +431,8 @@ def main():
             "arithmetic": {"f32": "v_mfma_f32_32x32x2_f32 (exact fp32)",
                            "bf16x6": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (split-bf16), fp32 accumulate",
                            "f16x3": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (amax-scaled split-fp16), fp32 accumulate",
-                           "f16": "1 x v_mfma_f32_32x32x16_f16 per product (amax-scaled fp16 operands), fp32 accumulate"}[precision],
+                           "f16": "1 x v_mfma_f32_32x32x16_f16 per product (amax-scaled fp16 operands), fp32 accumulate",
+                           "bf16": "1 x v_mfma_f32_32x32x16_bf16 per product on bf16 operands straight from HBM (LDS-DMA), fp32 accumulate"}[precision],
             "launches_per_step": launches // psteps, "avg_launch_ms": round(secs / launches * 1e3, 4),
             "fp32_equiv_dense_tflops": round(dense / secs / 1e12, 2), "fp32_equiv_executed_tflops": round(kept / secs / 1e12, 2),
             "all_contractions": {"fp32_equiv_dense_tflops": round(all_dense / all_secs / 1e12, 2),
@@ -436,6 +460,9 @@ def main():
     exact_leg = run_leg("f32") if (args.precision != "f32" and not args.no_exact_f32) else None
     # third leg, same --steps / --warmup: BASELINE.json configs[2] (16-bit MFMA arithmetic): fp16 operands, one MFMA per product
     c3_leg = run_leg("f16") if (args.precision == "f16x3" and not args.no_config3) else None
+    # fourth leg: BASELINE.json configs[2] AS STATED -- bf16 storage of activations / saved tensors / activation gradients (ops16)
+    s16_leg = run_leg("bf16") if (args.precision == "f16x3" and not args.no_bf16) else None
+    s16_peak_mem = round(torch.cuda.max_memory_allocated() / 2**30, 2) if s16_leg is not None else None
     ops.set_precision(args.precision)
 
     # secondary figure (outside the metric, which excludes the optimizer): the fused Adam step over
@@ -477,7 +504,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--clips", str(args.clips), "--precision", args.precision,
-               "--no-exact-f32", "--no-config3", "--no-cpu-baseline", "--no-other-mode"] + ([] if use_graph else ["--graph"])
+               "--no-exact-f32", "--no-config3", "--no-bf16", "--no-cpu-baseline", "--no-other-mode"] + ([] if use_graph else ["--graph"])
         env = {k: v for k, v in os.environ.items() if k not in ("GLF_BENCH_GRAPH", "GLF_BENCH_DUMP", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
         try:
             child = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -504,7 +531,9 @@ def main():
             "dtype": {"f32": "f32", "bf16x6": "f32 (split-bf16 x6 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16x3": "f32 (amax-scaled split-fp16 x3 MFMA, fp32 accumulate: fp32-equivalent)",
                       "f16": "f16 operands (amax-scaled, one MFMA per product), fp32 accumulate, fp32 storage: NOT fp32-equivalent "
-                             "(BASELINE.json configs[2], the 16-bit configuration)"}[args.precision], "data": "synthetic",
+                             "(BASELINE.json configs[2], the 16-bit configuration)",
+                      "bf16": "bf16 storage (activations, saved tensors, activation gradients), one bf16 MFMA per product, fp32 accumulate, fp32 "
+                              "master weights: NOT fp32-equivalent (BASELINE.json configs[2])"}[args.precision], "data": "synthetic",
             "config": {"workload": f"C2: (B,V,T,H,W)=({args.clips},3,16,112,112) per GPU, views 1/3/4, fp32 train() fwd + sum-BCE + bwd",
                        "global_batch_clips": args.clips * world, "frames_per_view_per_gpu": n_frames, "precision": args.precision,
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU",
@@ -520,7 +549,10 @@ def main():
                                   "under this mode; the exact-fp32 step is reported as exact_f32",
                          "f16": "fp32 tensors in HBM; every contraction operand is rounded to fp16 (11 bits) after a per-tensor power-of-two "
                                 "scale, one MFMA per product, fp32 accumulate; parity is judged at the looser tolerance written in "
-                                "tests/test_gpu_model.py::test_f16_mode_parity, never as the fp32 headline"}[args.precision],
+                                "tests/test_gpu_model.py::test_f16_mode_parity, never as the fp32 headline",
+                         "bf16": "bf16 tensors in HBM (activations, saved-for-backward, activation gradients), fp32 master weights / weight gradients / "
+                                 "statistics, one bf16 MFMA per product, fp32 accumulate; parity at the tolerances written in tests/test_gpu_s16.py, "
+                                 "never as the fp32 headline"}[args.precision],
             "loss": main_leg["loss"], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
             "roofline": roofline_of(main_leg),
         }
@@ -538,6 +570,15 @@ def main():
                                           "power-of-two scale), ONE v_mfma_f32_32x32x16_f16 per product; not fp32-equivalent (tolerances: "
                                           "tests/test_gpu_model.py::test_f16_mode_parity); activations stay fp32 in HBM",
                                   "roofline": roofline_of(c3_leg)}
+        if s16_leg is not None:
+            out["config3_bf16"] = {"value": round(args.clips * world * args.steps / s16_leg["dt"], 4), "unit": "clips/s",
+                                   "ms_per_step": round(s16_leg["dt"] / args.steps * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
+                                   "dtype": "bf16 storage / bf16 MFMA operands / fp32 accumulate / fp32 master weights", "loss": s16_leg["loss"],
+                                   "note": "BASELINE.json configs[2] as stated: the same step with every activation, saved-for-backward tensor and "
+                                           "activation gradient stored as bf16 in HBM (glfusion_amd.ops16; csrc/gemm_s16.hip, csrc/s16_ops.hip), ONE "
+                                           "v_mfma_f32_32x32x16_bf16 per product on operands staged global -> LDS by LDS-DMA; NOT fp32-equivalent and "
+                                           "never the headline (tolerances: tests/test_gpu_s16.py)",
+                                   "roofline": roofline_of(s16_leg)}
         out["optimizer_step"] = optimizer_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

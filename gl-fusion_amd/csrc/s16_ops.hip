@@ -62,18 +62,25 @@ __device__ __forceinline__ float bn_val(float x, float mu, float is, float ga, f
 constexpr int RT = 256;
 
 __host__ __device__ inline int red_slices(int rows, int c) {
-    // enough workgroups to stream at the HBM rate, few enough that the per-column atomics (one per slice) stay cheap
-    int s = (rows + 63) / 64;
-    int cap = (1 << 19) / (c > 0 ? c : 1);
-    if (cap < 64) cap = 64;
-    if (cap > 512) cap = 512;
+    // A workgroup streams `per` rows of all its channels; the grid must put enough loads in flight to reach the HBM rate (these
+    // reductions are latency-bound at low occupancy: 512 workgroups of 12 dependent iterations each ran at 1 TB/s), so: ~64 rows
+    // per row lane, at most 1 024 workgroups (one f64 atomic per column and slice).
+    const int c8 = c > 8 ? c / 8 : 1;
+    const int tpr = c8 < 256 ? c8 : 256;
+    const int rpp = 256 / tpr;                        // rows per pass of a workgroup
+    int s = (rows + 16 * rpp - 1) / (16 * rpp);       // 16 rows per thread
+    const int cblocks = (c8 + tpr - 1) / tpr;
+    int cap = 1024 / cblocks;
+    if (cap < 1) cap = 1;
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
-// generic two-value column reduction over rows: op(r, c8, a[8], b[8]); grid (slices, channel blocks)
+// generic two-value column reduction over rows: op(r, c8, a[8], b[8]); grid (slices, channel blocks).  Per thread: fp32 partial
+// sums over its <= ~16-64 rows, four rows' loads in flight at a time; the row lanes of a workgroup are folded in double through LDS
+// and ONE f64 atomic per column, statistic and workgroup reaches memory.
 template <class Op>
 __global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ sums) {
-    __shared__ double sh[RT * 16];
+    __shared__ float sh[RT * 16];
     const int tid = threadIdx.x;
     const int c8 = c >> 3;
     const int tpr = c8 < RT ? c8 : RT;            // threads per row
@@ -84,30 +91,40 @@ __global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int 
     const int r0 = slice * per, r1 = min(rows, r0 + per);
     for (int cb = blockIdx.y * tpr; cb < c8; cb += gridDim.y * tpr) {
         const int cc = cb + ct;
-        double acc[16];
+        float acc[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0;
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
         if (cc < c8 && rl < rpp) {
-            for (int r = r0 + rl; r < r1; r += rpp) {
+            int r = r0 + rl;
+            for (; r + 3 * rpp < r1; r += 4 * rpp) {
+                float a0[8], b0[8], a1[8], b1[8], a2[8], b2[8], a3[8], b3[8];
+                op(r, cc * 8, a0, b0); op(r + rpp, cc * 8, a1, b1); op(r + 2 * rpp, cc * 8, a2, b2); op(r + 3 * rpp, cc * 8, a3, b3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[j] += (a0[j] + a1[j]) + (a2[j] + a3[j]); acc[8 + j] += (b0[j] + b1[j]) + (b2[j] + b3[j]); }
+            }
+            for (; r < r1; r += rpp) {
                 float a[8], b[8];
                 op(r, cc * 8, a, b);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { acc[j] += a[j]; acc[8 + j] += b[j]; }
             }
         }
+        // fold the row lanes through LDS ([statistic][row lane][column]) and let consecutive threads own consecutive COLUMNS: a wave's
+        // 64 atomics then cover 512 contiguous bytes (scattered f64 atomics -- one thread adding its 8 columns, lanes 64 bytes
+        // apart -- ran at a tenth of that rate and were most of this kernel's time)
+        const int ncol = tpr * 8;
+        if (rl < rpp) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sh[tid * 16 + j] = acc[j];
+            for (int j = 0; j < 8; ++j) { sh[(0 * rpp + rl) * ncol + ct * 8 + j] = acc[j]; sh[(1 * rpp + rl) * ncol + ct * 8 + j] = acc[8 + j]; }
+        }
         __syncthreads();
-        if (rl == 0 && cc < c8) {
-            for (int q = 1; q < rpp; ++q) {
-                const int o = (q * tpr + ct) * 16;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] += sh[o + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(sums + cc * 8 + j, acc[j]);
-                atomicAdd(sums + c + cc * 8 + j, acc[8 + j]);
+        for (int idx = tid; idx < 2 * ncol; idx += RT) {
+            const int st = idx / ncol, col = idx - st * ncol;
+            const int gc = cb * 8 + col;
+            if (gc < c) {
+                double d = 0;
+                for (int q = 0; q < rpp; ++q) d += sh[(st * rpp + q) * ncol + col];
+                atomicAdd(sums + st * c + gc, d);
             }
         }
         __syncthreads();
@@ -431,12 +448,20 @@ __global__ __launch_bounds__(256) void s16_bn_res_ln_bwd_kernel(const u16* __res
     for (int ch = threadIdx.x; ch < c; ch += 256) { dst[ch] = sh[ch]; dst[c + ch] = sh[2048 + ch]; }
 }
 __global__ __launch_bounds__(256) void s16_ln_param_finalize(const float* __restrict__ slab, int nslab, int c, float* __restrict__ dg, float* __restrict__ db) {
-    // one thread per (statistic, channel), slabs added in order in double: bitwise reproducible
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * c) return;
+    // a workgroup = 16 (statistic, channel) columns x 16 slab lanes; every lane adds its slabs in order in double, lane 0 folds the
+    // 16 lane sums in order: a fixed summation tree => bitwise reproducible
+    __shared__ double sh[256];
+    const int cx = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cx;
     double s = 0;
-    for (int k = 0; k < nslab; ++k) s += slab[(long long)k * 2 * c + i];
-    if (i < c) dg[i] = (float)s; else db[i - c] = (float)s;
+    if (i < 2 * c)
+        for (int k = lane; k < nslab; k += 16) s += slab[(long long)k * 2 * c + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && i < 2 * c) {
+        for (int l = 1; l < 16; ++l) s += sh[l * 16 + cx];
+        if (i < c) dg[i] = (float)s; else db[i - c] = (float)s;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -513,19 +538,30 @@ __global__ __launch_bounds__(256) void s16_maxpool_bwd_kernel(const u16* __restr
 // y[n][c] = scale * sum_p x[n][p][c]   (x row stride ld); y bf16 or fp32 (the ASPP pooled branch keeps its N per-frame vectors
 // in fp32: its BatchNorm normalises over the N frames, whose averages differ by less than a few bf16 steps)
 __global__ __launch_bounds__(256) void s16_sum_rows_kernel(const u16* __restrict__ x, int ld, void* __restrict__ yv, int y_f32, float scale, int p, int c) {
-    __shared__ float sh[256];
+    // workgroup = 32 channel groups of 8 x 8 row lanes; grid (c / 256, n)
+    __shared__ float sh[256 * 8];
     const int n = blockIdx.y;
-    const int c0 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int pl = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c0 < c)
-        for (int r = pl; r < p; r += 4) s += bf2f(x[((long long)n * p + r) * ld + c0]);
-    sh[threadIdx.x] = s;
+    const int cg = blockIdx.x * 32 + (threadIdx.x & 31);       // group of 8 channels
+    const int pl = threadIdx.x >> 5;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cg * 8 < c)
+        for (int r = pl; r < p; r += 8) {
+            const F8 v = ld8(x + ((long long)n * p + r) * ld + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v.v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j * 256 + threadIdx.x] = s[j];
     __syncthreads();
-    if (pl == 0 && c0 < c) {
-        const float v = scale * (sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
-        if (y_f32) static_cast<float*>(yv)[(long long)n * c + c0] = v;
-        else static_cast<u16*>(yv)[(long long)n * c + c0] = f2bf(v);
+    if (pl == 0 && cg * 8 < c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = s[j];
+            for (int q = 1; q < 8; ++q) v += sh[j * 256 + q * 32 + (threadIdx.x & 31)];
+            v *= scale;
+            if (y_f32) static_cast<float*>(yv)[(long long)n * c + cg * 8 + j] = v;
+            else static_cast<u16*>(yv)[(long long)n * c + cg * 8 + j] = f2bf(v);
+        }
     }
 }
 __global__ __launch_bounds__(256) void s16_bcast_rows_kernel(const void* __restrict__ xv, int x_f32, u16* __restrict__ y, int ld, float scale, int p, int c8, long long total8) {
@@ -785,7 +821,7 @@ extern "C" int glf_s16_bn_res_ln_bwd(const void* dz, const void* w, const void* 
                        static_cast<const u16*>(x), bn_mean, bn_invstd, bn_gamma, bn_beta, ln_gamma, row_mean, row_rstd, static_cast<u16*>(du), workspace,
                        rows, c);
     if (int rc = glf::check_launch("s16_bn_res_ln_bwd")) return rc;
-    hipLaunchKernelGGL(s16_ln_param_finalize, dim3((2 * c + 255) / 256), dim3(256), 0, glf::S(s), workspace, nslab, c, dln_gamma, dln_beta);
+    hipLaunchKernelGGL(s16_ln_param_finalize, dim3((2 * c + 15) / 16), dim3(256), 0, glf::S(s), workspace, nslab, c, dln_gamma, dln_beta);
     return glf::check_launch("s16_ln_param_finalize");
 }
 
@@ -815,9 +851,10 @@ extern "C" int glf_s16_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void
 extern "C" int glf_s16_sum_rows(const void* x, int ldx, void* y, int y_dtype, float scale, int n, int p, int c, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x && y, GLF_ERR_NULL, "s16_sum_rows: null argument");
-    GLF_REQUIRE(n > 0 && p > 0 && c > 0, GLF_ERR_BAD_SHAPE, "s16_sum_rows: bad extents");
+    GLF_REQUIRE(n > 0 && p > 0, GLF_ERR_BAD_SHAPE, "s16_sum_rows: bad extents");
+    REQ_C8(c); REQ_AL(x, "x"); REQ_LD(ldx, "ldx");
     GLF_REQUIRE(y_dtype == GLF_DT_F32 || y_dtype == GLF_DT_BF16, GLF_ERR_UNSUPPORTED, "s16_sum_rows: y_dtype must be GLF_DT_F32 or GLF_DT_BF16");
-    hipLaunchKernelGGL(s16_sum_rows_kernel, dim3((c + 63) / 64, n), dim3(256), 0, glf::S(s), static_cast<const u16*>(x), ldx, y, y_dtype == GLF_DT_F32, scale, p, c);
+    hipLaunchKernelGGL(s16_sum_rows_kernel, dim3((c + 255) / 256, n), dim3(256), 0, glf::S(s), static_cast<const u16*>(x), ldx, y, y_dtype == GLF_DT_F32, scale, p, c);
     return glf::check_launch("s16_sum_rows");
 }
 extern "C" int glf_s16_bcast_rows(const void* x, int x_dtype, void* y, int ldy, float scale, int n, int p, int c, glf_stream_t s) {

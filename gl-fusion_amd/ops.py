@@ -382,6 +382,14 @@ def refresh_weights(frozen=None) -> None:
             reg.refresh()
 
 
+def reset_weight_images() -> None:
+    """Forget every registered weight-derived image (they are rebuilt lazily by their caches): after a change of precision the
+    images of the previous one would otherwise keep being refreshed with every update."""
+    for reg in _wreg.values():
+        for key in list(reg.images):
+            reg.drop(key)
+
+
 def freeze_weight_table(params) -> dict:
     """{device: frozen job table} of every image currently registered for the given parameters (run a step first so that
     they exist).  The tables hold their buffers alive; pass the dict to refresh_weights(frozen=...)."""
