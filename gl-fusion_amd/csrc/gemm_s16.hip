@@ -60,18 +60,22 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 constexpr int TM = 256;                  // rows of a workgroup tile
-constexpr int TK = 64;                   // reduction depth of a stage
+constexpr int TK = 64;                   // reduction depth of a stage (tn kernel; rows kernel: template parameter TK_)
 constexpr int NTH = 512;
 constexpr int NSTAGE = 3;
-constexpr int A_STAGE = TM * TK * 2;     // 32 KiB
 
-template <int BN_> struct RowsCfg {
-    static constexpr int B_STAGE = BN_ * TK * 2;
+// TK_ = 64: 144 KiB of LDS, one workgroup per CU.  TK_ = 32: 72 KiB, TWO workgroups per CU (<= 128 registers): the second one's
+// main loop covers the first one's prologue and epilogue -- what the short reductions (K <= 512: 4-16 K-tiles between a cold
+// start and a 64 KiB store phase) are made of.
+template <int BN_, int TK_> struct RowsCfg {
+    static constexpr int A_STAGE = TM * TK_ * 2;
+    static constexpr int B_STAGE = BN_ * TK_ * 2;
     static constexpr int STAGE = A_STAGE + B_STAGE;
     static constexpr int WNC = BN_ / 2;               // columns of a wave's output tile
     static constexpr int NJ = WNC / 32;               // 32-column blocks per wave
     static constexpr int PS = WNC + 4;                // parked row stride in floats
-    static constexpr int PARK = 64 * PS * 4;          // bytes per wave
+    static constexpr int PARK_ROWS = TK_ == 64 ? 64 : 32;   // rows of its 64-row tile a wave parks at a time
+    static constexpr int PARK = PARK_ROWS * PS * 4;   // bytes per wave
     static constexpr int STATS_OFF = 8 * PARK;        // [4][BN][2] floats behind the parked tiles
     static constexpr size_t SMEM = (size_t)(NSTAGE * STAGE > STATS_OFF + 4 * BN_ * 2 * 4 ? NSTAGE * STAGE : STATS_OFF + 4 * BN_ * 2 * 4) + 16;
 };
@@ -79,13 +83,18 @@ template <int BN_> struct RowsCfg {
 // ----------------------------------------------------------------------------------------------------------------------
 // rows kernel (NT)
 // ----------------------------------------------------------------------------------------------------------------------
-template <bool GATHER, int BN_>
-__global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
-    using Cfg = RowsCfg<BN_>;
-    constexpr int NJ = Cfg::NJ, WNC = Cfg::WNC, PS = Cfg::PS;
-    constexpr int AJ = 4;                               // A: 32 instructions of 8 rows per stage, 4 per wave
-    constexpr int BJ = BN_ / 64;                        // B: BN / 8 instructions, BN / 64 per wave
+template <bool GATHER, int BN_, int TK_>
+__global__ __launch_bounds__(NTH, TK_ == 64 ? 2 : 4) void s16_rows_kernel(const S16Args args) {
+    using Cfg = RowsCfg<BN_, TK_>;
+    constexpr int NJ = Cfg::NJ, WNC = Cfg::WNC, PS = Cfg::PS, A_STAGE = Cfg::A_STAGE;
+    constexpr int ROWB = TK_ * 2;                       // bytes of an LDS row
+    constexpr int CPR = TK_ / 8;                        // 16-byte chunks per row (8 | 4)
+    constexpr int RPI = 64 / CPR;                       // rows per LDS-DMA wave instruction (8 | 16)
+    constexpr int AJ = TM / (8 * RPI);                  // A instructions per wave and stage (4 | 2)
+    constexpr int BJ = BN_ / (8 * RPI);                 // B instructions per wave and stage
+    static_assert(BJ >= 1, "BN_ x TK_ tile too small for eight loading waves");
     constexpr int PER = AJ + BJ;                        // LDS-DMA instructions a wave issues per stage
+    constexpr int KS = TK_ / 16;                        // 16-deep k-steps per stage
     const int pM = args.M, pN = args.N, pK = args.K, p_lda = args.lda, p_ldb = args.ldb, p_ldc = args.ldc;
     const int p_taps = args.taps, p_gather = args.gather;
     const int p_tiles_n = args.tiles_n;
@@ -129,29 +138,32 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
     const u16* __restrict__ B = args.B + (long long)bz * args.bsb;
 
     // ---- staging state: this lane's rows and its (source-side) swizzled chunk -----------------------------------------
-    const int lrow = lane >> 3, lch = lane & 7;          // 8 rows x 8 chunks per wave instruction
-    // A rows of this lane: wave * 32 + 8 j + lrow; their chunk swizzle ((row >> 1) & 7) = (4 j + (lrow >> 1)) & 7
+    const int lrow = lane / CPR, lch = lane % CPR;       // RPI rows x CPR chunks per wave instruction
+    // chunk swizzle of LDS row r: TK_ = 64 (128-byte rows): (r >> 1) & 7;  TK_ = 32 (64-byte rows): (r >> 2) & 3 -- conflict-free
+    // ds_read_b128 for the 32x32x16 operand map (row = lane & 31, chunk = 2 s + (lane >> 5)) in both cases
+    auto swz = [](int r) __attribute__((always_inline)) { return CPR == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    // A rows of this lane: wave * (AJ * RPI) + RPI j + lrow
     int a_rb[AJ], a_y[AJ], a_x[AJ];                      // gather: source pixel index / coordinates for tap offset (0, 0)
     long long a_off[AJ];                                 // plain: element offset of the row, -1 = overhang
     int a_sw[AJ];
     {
         int cn = 0, cy = 0, cx = 0;
         if (GATHER) {
-            const int m0 = tm * TM + wave * 32 + lrow, hw = r_h * r_w;
+            const int m0 = tm * TM + wave * (AJ * RPI) + lrow, hw = r_h * r_w;
             cn = m0 / hw;
             const int rem = m0 - cn * hw;
             cy = rem / r_w; cx = rem - cy * r_w;
         }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int m = tm * TM + wave * 32 + 8 * j + lrow;
-            a_sw[j] = (lch ^ ((4 * j + (lrow >> 1)) & 7)) * 8;
+            const int m = tm * TM + wave * (AJ * RPI) + RPI * j + lrow;
+            a_sw[j] = (lch ^ swz(wave * (AJ * RPI) + RPI * j + lrow)) * 8;
             if (GATHER) {
                 if (m < pMe) { a_rb[j] = cn; a_y[j] = r_y0 + cy; a_x[j] = r_x0 + cx; }
                 else { a_rb[j] = -1; a_y[j] = 0; a_x[j] = 0; }
                 a_off[j] = -1;
                 if (j < AJ - 1) {
-                    cx += 8;
+                    cx += RPI;
                     while (cx >= r_w) { cx -= r_w; ++cy; }
                     while (cy >= r_h) { cy -= r_h; ++cn; }
                 }
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
         __syncthreads();                                  // s_mask shares LDS with nothing else, but keep the read ahead of any reuse
     }
 
-    const int nkc = pK / TK;
+    const int nkc = pK / TK_;
     const int ntiles = __popc(mask) * nkc;
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -249,16 +261,16 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
             const u16* Bt = B + (long long)tap * p_tsb;
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
-                // B rows of this lane: wave * (8 BJ) + 8 j + lrow; swizzle ((row >> 1) & 7) with row = wave * 8 BJ + 8 j + lrow
-                const int rb = wave * (8 * BJ) + 8 * j + lrow;
+                // B rows of this lane: wave * (RPI BJ) + RPI j + lrow
+                const int rb = wave * (RPI * BJ) + RPI * j + lrow;
                 const int n = tn * BN_ + rb;
-                pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + (lch ^ ((rb >> 1) & 7)) * 8;
+                pb[j] = (n < pN ? Bt + (long long)n * p_ldb : p_zero) + (lch ^ swz(rb)) * 8;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < AJ; ++j) pa[j] += TK;
+            for (int j = 0; j < AJ; ++j) pa[j] += TK_;
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) pb[j] += TK;
+            for (int j = 0; j < BJ; ++j) pb[j] += TK_;
         }
     };
     auto issue = [&](int stage) __attribute__((always_inline)) {
@@ -270,24 +282,25 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
         for (int j = 0; j < BJ; ++j) glds16(pb[j], sb + j * 1024);
     };
 
-    // fragment offsets of this lane: row = lane & 31, 16-byte chunk (2 s + (lane >> 5)) ^ ((row >> 1) & 7), s = 0..3
+    // fragment offsets of this lane: row = lane & 31, 16-byte chunk (2 s + (lane >> 5)) ^ swz(row), s = 0 .. KS-1
+    // (wm, wn and the 32-row block offsets are multiples of 32 rows: they do not change swz)
     const int l31 = lane & 31, hh = lane >> 5;
-    const int sw = (l31 >> 1) & 7;
-    int fo[4];
+    const int sw = swz(l31);
+    int fo[KS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) fo[s] = l31 * 128 + (((2 * s + hh) ^ sw) << 4);
+    for (int s = 0; s < KS; ++s) fo[s] = l31 * ROWB + (((2 * s + hh) ^ sw) << 4);
 
     auto compute = [&](int stage) __attribute__((always_inline)) {
-        const unsigned char* ab = smem + stage * Cfg::STAGE + wm * 128;
-        const unsigned char* bb = smem + stage * Cfg::STAGE + A_STAGE + wn * 128;
+        const unsigned char* ab = smem + stage * Cfg::STAGE + wm * ROWB;
+        const unsigned char* bb = smem + stage * Cfg::STAGE + A_STAGE + wn * ROWB;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             bf16x8 bf[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * 128 + fo[s]);
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROWB + fo[s]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ab + i * 32 * 128 + fo[s]);
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ab + i * 32 * ROWB + fo[s]);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = GLF_MFMA_BF16(af, bf[j], acc[i][j]);
             }
@@ -321,29 +334,110 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
     __syncthreads();                                    // every wave is done with the stage buffers: they become parking space
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------
+    // A wave parks PARK_ROWS rows of its 64 x WNC tile in LDS (fp32, its own area) and writes them back out as whole 16-byte
+    // pieces of rows; with TK_ = 32 (72 KiB of LDS) that takes two rounds of 32 rows.
+    constexpr int PARK_ROWS = Cfg::PARK_ROWS, NH = 64 / PARK_ROWS, IB = PARK_ROWS / 32;
     float* park = reinterpret_cast<float*>(smem + wave * Cfg::PARK);
     const float p_alpha = args.alpha;
     const float* __restrict__ p_bias = args.bias;
     const bool stats = args.colstats != nullptr;
-    float cs[NJ], cq[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
-    const int row_l = 4 * hh;
+    float cs[NJ], cq[NJ], bv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+        cs[j] = 0.f; cq[j] = 0.f;
         const int col = tn * BN_ + wn + 32 * j + l31;
-        const float bv = (p_bias && col < pN) ? p_bias[col] : 0.f;
+        bv[j] = (p_bias && col < pN) ? p_bias[col] : 0.f;
+    }
+    const int row_l = 4 * hh;
+    unsigned char* __restrict__ Cb = reinterpret_cast<unsigned char*>(args.C);
+    const int esz = args.c_bf16 ? 2 : 4;
+    Cb += (long long)bz * args.bsc * esz;
+    const bool wide = (p_ldc % 8) == 0 && (pN % 8) == 0 && (reinterpret_cast<size_t>(args.C) % 16) == 0 && (args.bsc % 8) == 0;
+    auto out_row = [&](int row) __attribute__((always_inline)) -> long long {
+        if (p_rect != 2) return row;
+        const int hw = r_h * r_w;
+        const int n = row / hw, rem = row - n * hw;
+        const int yy = rem / r_w;
+        return ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
+    };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = 32 * i + (r & 3) + 8 * (r >> 2) + row_l;
-                const float v = p_alpha * acc[i][j][r] + bv;
-                park[rl * PS + 32 * j + l31] = v;
-                if (stats) {
-                    const bool ok = tm * TM + wm + rl < pMe;
-                    cs[j] += ok ? v : 0.f;
-                    cq[j] += ok ? v * v : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int i = h * IB + ii;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 32 * ii + (r & 3) + 8 * (r >> 2) + row_l;
+                    const float v = p_alpha * acc[i][j][r] + bv[j];
+                    park[rl * PS + 32 * j + l31] = v;
+                    if (stats) {
+                        const bool ok = tm * TM + wm + h * PARK_ROWS + rl < pMe;
+                        cs[j] += ok ? v : 0.f;
+                        cq[j] += ok ? v * v : 0.f;
+                    }
+                }
+            }
+        }
+        const int row_base = tm * TM + wm + h * PARK_ROWS;
+        if (wide) {
+            // bf16: 8 columns per lane (two ds_read_b128 -> one 16-byte store), WNC / 8 lanes per row; fp32: 4 columns per lane
+            const int cpl = args.c_bf16 ? 8 : 4;
+            const int lpr = WNC / cpl;                       // lanes per row
+            const int rpi = 64 / lpr;                        // rows per iteration
+            const int c0 = (lane % lpr) * cpl;
+            const int col = tn * BN_ + wn + c0;
+            int rl = lane / lpr;
+            for (int it = 0; it < PARK_ROWS / rpi; ++it, rl += rpi) {
+                const int row = row_base + rl;
+                if (row < pMe && col < pN) {
+                    const long long orow = out_row(row);
+                    const float4 v0 = *reinterpret_cast<const float4*>(park + rl * PS + c0);
+                    if (args.c_bf16) {
+                        const float4 v1 = *reinterpret_cast<const float4*>(park + rl * PS + c0 + 4);
+                        uint4 o;
+                        u16* dst = reinterpret_cast<u16*>(Cb) + orow * p_ldc + col;
+                        if (args.accumulate) {
+                            const uint4 old = *reinterpret_cast<const uint4*>(dst);
+                            o.x = pack_bf16(v0.x + __uint_as_float(old.x << 16), v0.y + __uint_as_float(old.x & 0xffff0000u));
+                            o.y = pack_bf16(v0.z + __uint_as_float(old.y << 16), v0.w + __uint_as_float(old.y & 0xffff0000u));
+                            o.z = pack_bf16(v1.x + __uint_as_float(old.z << 16), v1.y + __uint_as_float(old.z & 0xffff0000u));
+                            o.w = pack_bf16(v1.z + __uint_as_float(old.w << 16), v1.w + __uint_as_float(old.w & 0xffff0000u));
+                        } else {
+                            o.x = pack_bf16(v0.x, v0.y); o.y = pack_bf16(v0.z, v0.w); o.z = pack_bf16(v1.x, v1.y); o.w = pack_bf16(v1.z, v1.w);
+                        }
+                        *reinterpret_cast<uint4*>(dst) = o;
+                    } else {
+                        float* dst = reinterpret_cast<float*>(Cb) + orow * p_ldc + col;
+                        float4 o = v0;
+                        if (args.accumulate) {
+                            const float4 old = *reinterpret_cast<const float4*>(dst);
+                            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = o;
+                    }
+                }
+            }
+        } else {
+            // narrow / unaligned outputs: one element per lane and store
+            for (int rl = 0; rl < PARK_ROWS; ++rl) {
+                const int row = row_base + rl;
+                if (row >= pMe) break;
+                const long long orow = out_row(row);
+                for (int c = lane; c < WNC; c += 64) {
+                    const int col = tn * BN_ + wn + c;
+                    if (col >= pN) continue;
+                    float v = park[rl * PS + c];
+                    if (args.c_bf16) {
+                        u16* dst = reinterpret_cast<u16*>(Cb) + orow * p_ldc + col;
+                        if (args.accumulate) v += __uint_as_float((unsigned)*dst << 16);
+                        *dst = (u16)(pack_bf16(v, 0.f) & 0xffffu);
+                    } else {
+                        float* dst = reinterpret_cast<float*>(Cb) + orow * p_ldc + col;
+                        if (args.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -359,90 +453,10 @@ __global__ __launch_bounds__(NTH, 2) void s16_rows_kernel(const S16Args args) {
                 d[0] = cs[j]; d[1] = cq[j];
             }
         }
-    }
-    // rows back out of LDS in whole 16-byte pieces
-    unsigned char* __restrict__ Cb = reinterpret_cast<unsigned char*>(args.C);
-    const int esz = args.c_bf16 ? 2 : 4;
-    Cb += (long long)bz * args.bsc * esz;
-    const bool wide = (p_ldc % 8) == 0 && (pN % 8) == 0 && (reinterpret_cast<size_t>(args.C) % 16) == 0 && (args.bsc % 8) == 0;
-    if (wide) {
-        // bf16: 8 columns per lane (two ds_read_b128 -> one 16-byte store), WNC / 8 lanes per row; fp32: 4 columns per lane
-        const int cpl = args.c_bf16 ? 8 : 4;
-        const int lpr = WNC / cpl;                       // lanes per row
-        const int rpi = 64 / lpr;                        // rows per iteration
-        const int c0 = (lane % lpr) * cpl;
-        const int col = tn * BN_ + wn + c0;
-        int rl = lane / lpr;
-        for (int it = 0; it < 64 / rpi; ++it, rl += rpi) {
-            const int row = tm * TM + wm + rl;
-            if (row < pMe && col < pN) {
-                long long orow = row;
-                if (p_rect == 2) {
-                    const int hw = r_h * r_w;
-                    const int n = row / hw, rem = row - n * hw;
-                    const int yy = rem / r_w;
-                    orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
-                }
-                const float4 v0 = *reinterpret_cast<const float4*>(park + rl * PS + c0);
-                if (args.c_bf16) {
-                    const float4 v1 = *reinterpret_cast<const float4*>(park + rl * PS + c0 + 4);
-                    uint4 o;
-                    u16* dst = reinterpret_cast<u16*>(Cb) + orow * p_ldc + col;
-                    if (args.accumulate) {
-                        const uint4 old = *reinterpret_cast<const uint4*>(dst);
-                        o.x = pack_bf16(v0.x + __uint_as_float(old.x << 16), v0.y + __uint_as_float(old.x & 0xffff0000u));
-                        o.y = pack_bf16(v0.z + __uint_as_float(old.y << 16), v0.w + __uint_as_float(old.y & 0xffff0000u));
-                        o.z = pack_bf16(v1.x + __uint_as_float(old.z << 16), v1.y + __uint_as_float(old.z & 0xffff0000u));
-                        o.w = pack_bf16(v1.z + __uint_as_float(old.w << 16), v1.w + __uint_as_float(old.w & 0xffff0000u));
-                    } else {
-                        o.x = pack_bf16(v0.x, v0.y); o.y = pack_bf16(v0.z, v0.w); o.z = pack_bf16(v1.x, v1.y); o.w = pack_bf16(v1.z, v1.w);
-                    }
-                    *reinterpret_cast<uint4*>(dst) = o;
-                } else {
-                    float* dst = reinterpret_cast<float*>(Cb) + orow * p_ldc + col;
-                    float4 o = v0;
-                    if (args.accumulate) {
-                        const float4 old = *reinterpret_cast<const float4*>(dst);
-                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-                    }
-                    *reinterpret_cast<float4*>(dst) = o;
-                }
-            }
-        }
-    } else {
-        // narrow / unaligned outputs (N = 5, 1 ...): one element per lane and store
-        for (int rl = 0; rl < 64; ++rl) {
-            const int row = tm * TM + wm + rl;
-            if (row >= pMe) break;
-            long long orow = row;
-            if (p_rect == 2) {
-                const int hw = r_h * r_w;
-                const int n = row / hw, rem = row - n * hw;
-                const int yy = rem / r_w;
-                orow = ((long long)n * g_hd + r_y0 + yy) * g_wd + r_x0 + (rem - yy * r_w);
-            }
-            for (int c = lane; c < WNC; c += 64) {
-                const int col = tn * BN_ + wn + c;
-                if (col >= pN) continue;
-                float v = park[rl * PS + c];
-                if (args.c_bf16) {
-                    u16* dst = reinterpret_cast<u16*>(Cb) + orow * p_ldc + col;
-                    if (args.accumulate) v += __uint_as_float((unsigned)*dst << 16);
-                    *dst = (u16)(pack_bf16(v, 0.f) & 0xffffu);
-                } else {
-                    float* dst = reinterpret_cast<float*>(Cb) + orow * p_ldc + col;
-                    if (args.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
-        }
-    }
-    if (stats) {
         __syncthreads();
         if (tid < BN_) {
             const int col = tn * BN_ + tid;
             if (col < pN) {
-                const float* sst = reinterpret_cast<const float*>(smem + Cfg::STATS_OFF);
                 double s = 0, q = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { s += sst[(w * BN_ + tid) * 2]; q += sst[(w * BN_ + tid) * 2 + 1]; }
@@ -498,7 +512,6 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
     const int r0 = sl * chunk;
     const int r1 = min(pK, r0 + chunk);
     if (r0 >= r1) return;
-    const int ntiles = (r1 - r0 + TK - 1) / TK;
 
     // staging: A instruction j of this wave holds reduction rows wave * 8 + 2 j + (lane >> 5), 16-byte piece lane & 31 of the
     // 512-byte row; B instruction j rows wave * 8 + 4 j + (lane >> 4), piece lane & 15.  Source-side swizzle: the 64-byte chunk
@@ -524,50 +537,67 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
         const int ky = tap / g_kw, kx = tap - ky * g_kw;
         oy = ky * g_dil - g_pad; ox = kx * g_dil - g_pad;
     }
+    // per-lane element offsets of its rows relative to the tile's first row (the tile base is wave-uniform: scalar arithmetic)
+    long long a_base[AJ], b_base[BJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) a_base[j] = (long long)(wave * 8 + 2 * j + a_rl) * p_lda + (a_col[j] >= 0 ? a_col[j] : 0);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) b_base[j] = (long long)(wave * 8 + 4 * j + b_rl) * p_ldb + (b_col[j] >= 0 ? b_col[j] : 0);
     auto issue = [&](int stage, int rbase) __attribute__((always_inline)) {
         unsigned char* sa = smem + stage * TN_STAGE + (wave * AJ) * 1024;
         unsigned char* sb = smem + stage * TN_STAGE + TNA_STAGE + (wave * BJ) * 1024;
+        const u16* At = A + (long long)rbase * p_lda;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int r = rbase + wave * 8 + 2 * j + a_rl;
-            const u16* p = (r < r1 && a_col[j] >= 0) ? A + (long long)r * p_lda + a_col[j] : p_zero;
-            glds16(p, sa + j * 1024);
+            glds16((r < r1 && a_col[j] >= 0) ? At + a_base[j] : p_zero, sa + j * 1024);
         }
+        if (!GATHER) {
+            const u16* Bt = B + (long long)rbase * p_ldb;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int r = rbase + wave * 8 + 4 * j + b_rl;
-            long long src = -1;
-            if (r < r1 && b_col[j] >= 0) {
-                if (GATHER) {
+            for (int j = 0; j < BJ; ++j) {
+                const int r = rbase + wave * 8 + 4 * j + b_rl;
+                glds16((r < r1 && b_col[j] >= 0) ? Bt + b_base[j] : p_zero, sb + j * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int r = rbase + wave * 8 + 4 * j + b_rl;
+                long long src = -1;
+                if (r < r1 && b_col[j] >= 0) {
                     const int n = r / hw, rem = r - n * hw;
                     const int y = rem / g_wd, x = rem - y * g_wd;
                     const int sy = y * g_stride + oy, sx = x * g_stride + ox;
                     if ((unsigned)sy < (unsigned)g_hs && (unsigned)sx < (unsigned)g_ws) src = ((long long)n * g_hs + sy) * g_ws + sx;
-                } else {
-                    src = r;
                 }
+                glds16(src >= 0 ? B + src * p_ldb + b_col[j] : p_zero, sb + j * 1024);
             }
-            glds16(src >= 0 ? B + src * p_ldb + b_col[j] : p_zero, sb + j * 1024);
         }
     };
 
     // transposing fragment read (ds_read_b64_tr_b16): lanes 16 g .. 16 g + 15 fetch a block of 4 reduction rows x 16 columns;
     // lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3 and receives column (lane & 15), rows 0..3.
     // Group g: columns 16 (g & 1) .., reduction half g >> 1 (rows 8 (g >> 1) + q, and + 4 for the second read).
+    // Offsets: a k-step (16 rows) and the second read (4 rows) further on keep row & 3, hence the chunk swizzle: ONE base per
+    // fragment and lane, everything else is an immediate.
     const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int trow = 8 * (grp >> 1) + q;                 // row inside a 16-deep k-step (second read: + 4)
     const int tcolb = (16 * (grp & 1) + 4 * pp) * 2;     // byte offset of the 4 columns inside a 32-column block
-    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-    // byte offset of (row rr of the stage, byte column cb) inside an image with ROWB-byte rows: 64-byte chunk ^= rr & 3
 #define GLF_TR_OFF(rr, cb, ROWB) ((rr) * (ROWB) + ((((cb) >> 6) ^ ((rr) & 3)) << 6) + ((cb) & 63))
-#define GLF_TR_FRAG16(base, rr, cb, ROWB, dst)                                                                           \
-    {                                                                                                                     \
-        const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((base) + GLF_TR_OFF((rr), (cb), ROWB)));   \
-        const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((base) + GLF_TR_OFF((rr) + 4, (cb), ROWB))); \
-        typedef short s16x8_ __attribute__((ext_vector_type(8)));                                                         \
-        const s16x8_ both_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                                   \
-        dst = __builtin_bit_cast(bf16x8, both_);                                                                          \
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = GLF_TR_OFF(trow, (wm + 32 * i) * 2 + tcolb, 512);
+        fb[i] = TNA_STAGE + GLF_TR_OFF(trow, (wn + 32 * i) * 2 + tcolb, 256);
     }
+    // The transposing reads are issued as inline asm: through the builtin, hipcc orders every ds_read_b64_tr_b16 behind ALL
+    // outstanding LDS-DMA writes (s_waitcnt vmcnt(0) in front of the first read of each K-tile -- the loads of tile t+2, issued a
+    // moment earlier, were waited for on the spot and the three-stage pipeline ran as a serial load -> compute loop: 60 % of the
+    // wave time in waits, 580 TF where the rows kernel reaches 880).  What orders a read behind the DMA that filled ITS stage is the
+    // counted vmcnt + barrier at the top of the iteration.
+    typedef int v2i_ __attribute__((ext_vector_type(2)));
+#define GLF_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -576,16 +606,25 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
     auto compute = [&](int stage) __attribute__((always_inline)) {
-        const unsigned char* ab = smem + stage * TN_STAGE;
-        const unsigned char* bb = smem + stage * TN_STAGE + TNA_STAGE;
+        const unsigned sbase = lds0 + stage * TN_STAGE;
+        const unsigned aa0 = sbase + fa[0], aa1 = sbase + fa[1], ab0 = sbase + fb[0], ab1 = sbase + fb[1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int rr = 16 * s + trow;
+            v2i_ r[8];
+            GLF_TR_READ(r[0], ab0, s * 16 * 256);          GLF_TR_READ(r[1], ab0, s * 16 * 256 + 4 * 256);
+            GLF_TR_READ(r[2], ab1, s * 16 * 256);          GLF_TR_READ(r[3], ab1, s * 16 * 256 + 4 * 256);
+            GLF_TR_READ(r[4], aa0, s * 16 * 512);          GLF_TR_READ(r[5], aa0, s * 16 * 512 + 4 * 512);
+            GLF_TR_READ(r[6], aa1, s * 16 * 512);          GLF_TR_READ(r[7], aa1, s * 16 * 512 + 4 * 512);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
             bf16x8 bf[2], af[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) GLF_TR_FRAG16(bb, rr, (wn + 32 * j) * 2 + tcolb, 256, bf[j])
-#pragma unroll
-            for (int i = 0; i < 2; ++i) GLF_TR_FRAG16(ab, rr, (wm + 32 * i) * 2 + tcolb, 512, af[i])
+            for (int k = 0; k < 2; ++k) {
+                bf[k] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r[2 * k], r[2 * k + 1], 0, 1, 2, 3));
+                af[k] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r[4 + 2 * k], r[5 + 2 * k], 0, 1, 2, 3));
+            }
+            (void)sizeof(v4i_);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -594,26 +633,56 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
     };
     (void)s_any;
 
-    issue(0, r0);
-    if (ntiles > 1) issue(1, r0 + TK);
-    int st = 0, t = 0;
-    for (; t + 2 < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(st == 0 ? 2 : st - 1, r0 + (t + 2) * TK);
-        compute(st);
-        st = st == 2 ? 0 : st + 1;
+    // The tile sequence of this slice.  A gathered tap reads only output rows y whose source row y * stride + oy lies inside the
+    // map: [ylo, yhi) per image.  For the ASPP rates on a 28 x 28 map that band is 4 (rate 24) or 16 (rate 12) of 28 rows for six
+    // of the nine taps -- K-tiles outside it would multiply zero-page rows, so the cursor jumps over them (wave-uniform scalar
+    // arithmetic, two divisions per tile).
+    int ylo = 0, yhi = g_hd;
+    if (GATHER) {
+        ylo = oy < 0 ? (-oy + g_stride - 1) / g_stride : 0;
+        const int ymax = (g_hs - 1 - oy) / g_stride;           // largest y with y * stride + oy <= hs - 1 (oy <= hs - 1 for a kept tap)
+        yhi = (g_hs - 1 - oy) < 0 ? 0 : (ymax + 1 < g_hd ? ymax + 1 : g_hd);
+        if (ylo > yhi) ylo = yhi;
     }
-    if (t + 1 < ntiles) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-        __builtin_amdgcn_s_barrier();
-        compute(st);
-        st = st == 2 ? 0 : st + 1;
-        ++t;
+    const bool banded = GATHER && (ylo > 0 || yhi < g_hd);
+    auto next_valid = [&](int r) __attribute__((always_inline)) -> int {
+        if (!banded || r >= r1) return r;
+        if (ylo >= yhi) return r1;
+        const int n = r / hw, rem = r - n * hw;
+        const int y = rem / g_wd;
+        if (y < ylo) return n * hw + ylo * g_wd;
+        if (y >= yhi) return (n + 1) * hw + ylo * g_wd;
+        return r;
+    };
+    int cursor = __builtin_amdgcn_readfirstlane(next_valid(r0));
+    auto take = [&]() __attribute__((always_inline)) -> int {
+        const int r = cursor;
+        cursor = r < r1 ? __builtin_amdgcn_readfirstlane(next_valid(r + TK)) : r1;
+        return r;
+    };
+    int t0 = take();
+    if (t0 < r1) {
+        issue(0, t0);
+        int t1 = take();
+        bool has_next = t1 < r1;
+        if (has_next) issue(1, t1);
+        int st = 0;
+        for (;;) {
+            if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            bool has_next2 = false;
+            if (has_next) {
+                const int t2 = take();
+                has_next2 = t2 < r1;
+                if (has_next2) issue(st == 0 ? 2 : st - 1, t2);
+            }
+            compute(st);
+            if (!has_next) break;
+            has_next = has_next2;
+            st = st == 2 ? 0 : st + 1;
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    compute(st);
 
     // ---- epilogue: direct stores (32 consecutive columns per half wave) ----------------------------------------------------
     const float p_alpha = args.alpha;
@@ -722,10 +791,12 @@ int init_gemm_s16_attrs() {
 #define SET_ATTR(fn, bytes)                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
     if (e != hipSuccess) return fail(GLF_ERR_LAUNCH, "hipFuncSetAttribute(" #fn "): %s", hipGetErrorString(e));
-    SET_ATTR((s16_rows_kernel<false, 128>), RowsCfg<128>::SMEM)
-    SET_ATTR((s16_rows_kernel<true, 128>), RowsCfg<128>::SMEM)
-    SET_ATTR((s16_rows_kernel<false, 64>), RowsCfg<64>::SMEM)
-    SET_ATTR((s16_rows_kernel<true, 64>), RowsCfg<64>::SMEM)
+    SET_ATTR((s16_rows_kernel<false, 128, 64>), (RowsCfg<128, 64>::SMEM))
+    SET_ATTR((s16_rows_kernel<true, 128, 64>), (RowsCfg<128, 64>::SMEM))
+    SET_ATTR((s16_rows_kernel<false, 128, 32>), (RowsCfg<128, 32>::SMEM))
+    SET_ATTR((s16_rows_kernel<true, 128, 32>), (RowsCfg<128, 32>::SMEM))
+    SET_ATTR((s16_rows_kernel<false, 64, 64>), (RowsCfg<64, 64>::SMEM))
+    SET_ATTR((s16_rows_kernel<true, 64, 64>), (RowsCfg<64, 64>::SMEM))
     SET_ATTR((s16_tn_kernel<false>), SMEM_TN16)
     SET_ATTR((s16_tn_kernel<true>), SMEM_TN16)
 #undef SET_ATTR
@@ -760,12 +831,20 @@ extern "C" int glf_s16_gemm_nt(const void* A, const void* B, const float* bias, 
     GLF_REQUIRE(tiles_m * a.tiles_n < 2147483647LL, GLF_ERR_BAD_SHAPE, "s16_gemm_nt: grid out of range");
     dim3 grid((unsigned)(tiles_m * a.tiles_n), 1, p->batch);
     const bool gather = p->gather != 0;
+    // stage depth: 32 = two workgroups per CU (the default), 64 = one per CU with half the barriers; GLF_S16_TK=32|64 forces one
+    static const int tk_force = []() { const char* e = getenv("GLF_S16_TK"); return e ? atoi(e) : 0; }();
+    // measured (profiles/r04_s16_tk_ab.txt): two workgroups per CU win on every shape of the model (K = 256: +29 %, the 3x3 convs
+    // +13-18 %, the M = 150 528 projections +3 %) except the region-mode launches with many short region blocks (rate 12: -10 %)
+    const bool tk32 = bn == 128 && (tk_force ? tk_force == 32 : p->rect != 2);
     if (bn == 64) {
-        if (gather) hipLaunchKernelGGL((s16_rows_kernel<true, 64>), grid, dim3(NTH), RowsCfg<64>::SMEM, glf::S(stream), a);
-        else hipLaunchKernelGGL((s16_rows_kernel<false, 64>), grid, dim3(NTH), RowsCfg<64>::SMEM, glf::S(stream), a);
+        if (gather) hipLaunchKernelGGL((s16_rows_kernel<true, 64, 64>), grid, dim3(NTH), (RowsCfg<64, 64>::SMEM), glf::S(stream), a);
+        else hipLaunchKernelGGL((s16_rows_kernel<false, 64, 64>), grid, dim3(NTH), (RowsCfg<64, 64>::SMEM), glf::S(stream), a);
+    } else if (tk32) {
+        if (gather) hipLaunchKernelGGL((s16_rows_kernel<true, 128, 32>), grid, dim3(NTH), (RowsCfg<128, 32>::SMEM), glf::S(stream), a);
+        else hipLaunchKernelGGL((s16_rows_kernel<false, 128, 32>), grid, dim3(NTH), (RowsCfg<128, 32>::SMEM), glf::S(stream), a);
     } else {
-        if (gather) hipLaunchKernelGGL((s16_rows_kernel<true, 128>), grid, dim3(NTH), RowsCfg<128>::SMEM, glf::S(stream), a);
-        else hipLaunchKernelGGL((s16_rows_kernel<false, 128>), grid, dim3(NTH), RowsCfg<128>::SMEM, glf::S(stream), a);
+        if (gather) hipLaunchKernelGGL((s16_rows_kernel<true, 128, 64>), grid, dim3(NTH), (RowsCfg<128, 64>::SMEM), glf::S(stream), a);
+        else hipLaunchKernelGGL((s16_rows_kernel<false, 128, 64>), grid, dim3(NTH), (RowsCfg<128, 64>::SMEM), glf::S(stream), a);
     }
     return glf::check_launch("s16_gemm_nt");
 }

@@ -93,12 +93,19 @@ def gemm16(mode: str, A: torch.Tensor, B: torch.Tensor, Cm: torch.Tensor, *, M: 
 
 
 def tn_split16(rows: int, m: int, n: int, ntaps: int, batch: int = 1) -> int:
-    """Reduction slices of glf_s16_gemm_tn: 256 x 128 tiles, one workgroup per CU; aim for ~2 rounds of the 256 CUs, keep at
-    least 512 rows per slice (every slice costs an [M][N] fp32 slab written and read back)."""
+    """Reduction slices of glf_s16_gemm_tn: 256 x 128 tiles, one workgroup per CU.  Aim for ~2 rounds of the 256 CUs and, among the
+    slice counts around that, take the one whose workgroups fill whole rounds best (576 workgroups = 2.25 rounds run as long as
+    768 = 3); keep at least 512 rows per slice (every slice costs an [M][N] fp32 slab written and read back)."""
     tiles = ((m + 255) // 256) * ((n + 127) // 128) * max(ntaps, 1) * batch
     want = max(1, (512 + tiles - 1) // tiles)
-    cap = max(1, rows // 512)
-    return int(max(1, min(want, cap, 65535 // max(batch, 1))))
+    cap = max(1, min(rows // 512, 65535 // max(batch, 1)))
+    best, best_score = min(want, cap), -1.0
+    for sp in range(max(1, want // 2), max(1, min(2 * want, cap)) + 1):
+        b = tiles * sp
+        score = b / (((b + 255) // 256) * 256.0) - 0.01 * sp
+        if score > best_score:
+            best, best_score = sp, score
+    return int(max(1, min(best, cap)))
 
 
 def s16_conv_ok(cin: int, cout: int) -> bool:

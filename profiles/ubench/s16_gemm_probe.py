@@ -153,7 +153,7 @@ def timeit(fn, iters=20):
 
 def perf():
     print("---- throughput (random data) ----")
-    for (M, N, K) in [(150528, 3072, 2048), (150528, 2048, 1024), (50176, 2048, 512), (50176, 512, 2048), (50176, 256, 1024), (50176, 1024, 256),
+    for (M, N, K) in [(150528, 3072, 2048), (50176, 256, 256), (50176, 512, 512), (150528, 2048, 1024), (50176, 2048, 512), (50176, 512, 2048), (50176, 256, 1024), (50176, 1024, 256),
                       (50176, 256, 2048), (193600, 256, 64), (193600, 64, 256), (8192, 8192, 8192)]:
         A = torch.randn(M, K, device=dev).to(BF)
         B = torch.randn(N, K, device=dev).to(BF)
@@ -187,8 +187,30 @@ def perf():
         print(f"conv3x3 {cin}->{cout} d{dil} rect{rect}: {ms:.3f} ms  dense-equivalent {2.0 * n * h * h * cout * cin * 9 / ms / 1e9:.0f} TF")
 
 
+def one(kind):
+    """a single large launch, ten times: the target of rocprofv3 --pmc runs"""
+    M, N, K = 150528, 3072, 2048
+    if kind == "nt":
+        A = torch.randn(M, K, device=dev).to(BF); B = torch.randn(N, K, device=dev).to(BF); Cm = torch.empty(M, N, dtype=BF, device=dev)
+        p = params(M, N, K, K, K, N)
+        for _ in range(10):
+            check(lib.glf_s16_gemm_nt(P(A), P(B), None, P(Cm), C.byref(p), S()), "nt")
+    else:
+        A = torch.randn(M, N, device=dev).to(BF); B = torch.randn(M, K, device=dev).to(BF); Cm = torch.empty(N, K, dtype=torch.float32, device=dev)
+        p = params(N, K, M, N, K, K, split=4, c_bf16=False)
+        nb = int(lib.glf_s16_gemm_tn_workspace_bytes(C.byref(p)))
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        p.workspace, p.workspace_bytes = P(ws), nb
+        for _ in range(10):
+            check(lib.glf_s16_gemm_tn(P(A), P(B), P(Cm), C.byref(p), S()), "tn")
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--one" in sys.argv:
+        one(sys.argv[sys.argv.index("--one") + 1])
+        sys.exit(0)
     plain_case(300, 136, 128)
     plain_case(1000, 64, 64, bias=True)
     plain_case(513, 256, 192, batch=3, alpha=0.5, c_bf16=False)
