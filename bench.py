@@ -351,6 +351,19 @@ def main():
         if not (loss_val == loss_val and abs(loss_val) != float("inf")):
             raise SystemExit(f"non-finite loss {loss_val} ({precision})")
         allreduce_ms = round(reducer.last_allreduce_ms(), 3) if (world > 1 and sg is not None and reducer.last_allreduce_ms() is not None) else None
+        comm = None
+        if world > 1 and sg is None:
+            # eager (immediate) mode: buckets are all-reduced while backward is still running.  GPU-clock figures of the LAST timed step
+            # (events recorded by the reducer anyway; read here, after the timed region): the window from the first collective's
+            # enqueue to the last one's completion, the part of it that lies after the last backward kernel (= what the step waited
+            # for), and per bucket how many of the gradients were in place when its collective was enqueued
+            ec = reducer.eager_comm_ms()
+            if ec is not None:
+                allreduce_ms = round(ec[0], 3)
+                comm = {"comm_window_ms": round(ec[0], 3), "exposed_comm_ms": round(ec[1], 3),
+                        "bucket_enqueue_progress": [[b, fired, total] for b, fired, total in reducer.overlap_log],
+                        "gradient_elements_in_place_frac": round(reducer.in_place_elems / max(1, reducer.in_place_elems + reducer.copied_elems), 4),
+                        "note": "bucket_enqueue_progress: [bucket, gradients produced when its all-reduce was enqueued, gradients in all]"}
         if sg is not None:
             sg.release()
             sg = None
@@ -383,7 +396,7 @@ def main():
         fence()
         ops.PROFILER = None
         ops.STREAMS = streams
-        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "host_first": host_first, "allreduce_ms": allreduce_ms}
+        return {"precision": precision, "dt": dt, "loss": loss_val, "prof": prof, "iso_steps": iso_steps, "host": host, "host_first": host_first, "allreduce_ms": allreduce_ms, "comm": comm}
 
     def roofline_of(leg):
         precision, prof, psteps, dt = leg["precision"], leg["prof"], leg["iso_steps"], leg["dt"]
@@ -539,6 +552,8 @@ def main():
                        "parallelism": f"dp{world} (frames sharded, RCCL grad all-reduce)" if world > 1 else "single GPU",
                        "ranks_in_collective": ranks_seen,
                        "allreduce_ms_per_step": main_leg.get("allreduce_ms"),
+                       "exposed_comm_ms": (main_leg.get("comm") or {}).get("exposed_comm_ms"),
+                       "comm": main_leg.get("comm"),
                        "collective_backend": (os.environ.get("GLF_DIST_BACKEND", "nccl") if world > 1 else None)},
             "numerics": {"f32": "exact fp32 MFMA",
                          "bf16x6": "fp32 operands and results; each product = 6 bf16 MFMAs on an exact 3-way split, fp32 accumulate; "

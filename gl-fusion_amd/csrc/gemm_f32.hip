@@ -607,12 +607,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
             const long long row = i / n4;
             const int c4 = (int)(i - row * n4) * 4;
             float* dst = C + row * ldc + c4;
-            float4 acc = accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (the slabs are added in double: the second stage must not add a rounding walk of its own to the slices' fp32 chains)
+            double ax = 0, ay = 0, az = 0, aw = 0;
+            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); ax = o.x; ay = o.y; az = o.z; aw = o.w; }
             const float* sp = src + row * N + c4;
             for (int sl = 0; sl < nvalid; ++sl) {
                 const float4 v = *reinterpret_cast<const float4*>(sp + sl * slice_stride);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                ax += v.x; ay += v.y; az += v.z; aw += v.w;
             }
+            const float4 acc = make_float4((float)ax, (float)ay, (float)az, (float)aw);
             *reinterpret_cast<float4*>(dst) = acc;
             cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
         }
@@ -621,8 +624,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
             const long long row = i / N;
             const int col = (int)(i - row * N);
             float* dst = C + row * ldc + col;
-            float acc = accumulate ? *dst : 0.f;
-            for (int sl = 0; sl < nvalid; ++sl) acc += src[sl * slice_stride + i];
+            double accd = accumulate ? (double)*dst : 0.0;
+            for (int sl = 0; sl < nvalid; ++sl) accd += src[sl * slice_stride + i];
+            const float acc = (float)accd;
             *dst = acc;
             cmax = fmaxf(cmax, fabsf(acc));
         }

@@ -39,6 +39,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.fired = [False] * len(params)   # whose post-accumulate hook ran this step
+        self.fired_capture = None            # deferred mode: the hooks that ran while the step was RECORDED (they do not run on a replay)
         self.work = None
         self.events = []        # one per gradient copied on a GPU stream (the model runs its views on side streams)
 
@@ -83,6 +84,8 @@ class GradAllReducer:
         self.overlap_log = []          # per launched bucket: (bucket index, gradients in place when its collective was enqueued, total)
         self._fired_count = 0
         self.allreduce_ms = None       # deferred mode: GPU time of the last finalize()'s collectives (timed with events)
+        self._first_launch_ev = None   # eager mode: event recorded when the step's first collective was enqueued
+        self._eager_events = None      # eager mode: (first enqueue, end of backward, last collective done) of the latest finalize()
         self._handles = []
         # deferred mode (engine.StepGraph): the hooks only copy gradients into the buckets -- work a hipGraph capture can
         # record -- and every collective is launched by finalize(), after backward (after the graph replay), on the current
@@ -107,6 +110,9 @@ class GradAllReducer:
                 cur.wait_event(e)
             b.events = []
         self.overlap_log.append((self.buckets.index(b), self._fired_count, len(self._where)))
+        if self._first_launch_ev is None and b.flat.is_cuda:
+            self._first_launch_ev = torch.cuda.Event(enable_timing=True)
+            self._first_launch_ev.record(torch.cuda.current_stream(b.flat.device))
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p: torch.nn.Parameter) -> None:
@@ -144,7 +150,21 @@ class GradAllReducer:
             from . import ops
             ops.release_grad_slots(self._slots)
         if self.deferred:
-            # slices of parameters that never fire stay zero (the flat buffer starts zeroed and nothing writes them)
+            # The hooks run while the step is RECORDED (warm-up + capture), not on a replay: which parameters take part is fixed at
+            # the first finalize() after the capture.  Slices of parameters that never fire must contribute zeros -- the collective is
+            # in place, so whatever an earlier (eager or warm-up) step left there would be re-reduced on every replay: they are
+            # zero-filled before the collectives.
+            for b in self.buckets:
+                if b.fired_capture is None or any(b.fired):
+                    b.fired_capture = [a or c for a, c in zip(b.fired, b.fired_capture or [False] * len(b.params))]
+                b.fired = [False] * len(b.params)
+                b.pending = len(b.params)
+                b.work = None
+                b.events = []
+                for i, p in enumerate(b.params):
+                    if not b.fired_capture[i]:
+                        off = b.offsets[i]
+                        b.flat[off:off + p.numel()].zero_()
             ev = None
             if self.buckets and self.buckets[0].flat.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -159,11 +179,19 @@ class GradAllReducer:
                 if self.average:
                     b.flat.div_(self.world)
                 for i, p in enumerate(b.params):
-                    if b.fired[i]:
+                    if b.fired_capture[i]:
                         off = b.offsets[i]
                         p.grad = b.flat[off:off + p.numel()].view_as(p)
             return
+        for b in self.buckets:
+            b.fired_capture = None           # (back in eager mode: a later capture starts from its own record)
         self.overlap_log = self.overlap_log[-len(self.buckets):]
+        cuda = bool(self.buckets) and self.buckets[0].flat.is_cuda
+        ev_bwd = None
+        if cuda:
+            # everything backward enqueued on this stream is ahead of this event: what the step waits for AFTER it is communication
+            ev_bwd = torch.cuda.Event(enable_timing=True)
+            ev_bwd.record()
         for b in self.buckets:
             if b.work is None:
                 for i, p in enumerate(b.params):
@@ -172,7 +200,7 @@ class GradAllReducer:
                         b.flat[off:off + p.numel()].zero_()
                 self._launch(b)
         for b in self.buckets:
-            b.work.wait()
+            b.work.wait()                  # (GPU: the CURRENT stream -- the one the optimizer runs on -- waits for the collective)
             if self.average:
                 b.flat.div_(self.world)
             for i, p in enumerate(b.params):
@@ -182,6 +210,21 @@ class GradAllReducer:
             b.pending = len(b.params)
             b.fired = [False] * len(b.params)
             b.work = None
+        if cuda:
+            ev_done = torch.cuda.Event(enable_timing=True)
+            ev_done.record()
+            self._eager_events = (self._first_launch_ev, ev_bwd, ev_done)
+        self._first_launch_ev = None
+
+    def eager_comm_ms(self):
+        """Eager (immediate) mode, after a finalize(): (comm_window_ms, exposed_comm_ms) on the GPU clock -- the time from the
+        enqueue of the step's FIRST bucket collective to the completion of the last one, and the part of it that lies AFTER the
+        last backward kernel (what the step actually waits for; 0 when every collective finished under backward).  Synchronises."""
+        ev = self._eager_events
+        if ev is None or ev[0] is None:
+            return None
+        ev[2].synchronize()
+        return ev[0].elapsed_time(ev[2]), ev[1].elapsed_time(ev[2])
 
     def last_allreduce_ms(self) -> Optional[float]:
         """GPU time between the first collective's enqueue and the last one's completion in the latest deferred finalize()

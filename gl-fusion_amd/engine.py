@@ -89,25 +89,34 @@ class StepGraph:
 
         self.stream = torch.cuda.Stream(device=dev)            # warm-up and capture share it (library rings, pools, allocator)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(1, warmup)):                    # lazily-created state (caches, job table, rings) settles here
-                out = body()
-                if reducer is not None:
-                    reducer.finalize()
-            del out
-            torch.cuda.synchronize(dev)
-            for p in self.params:
-                p.grad = None
-            ops.reset_capture_pools()
-            if refresh_weights:
-                # the captured refresh replays against a table of its own: it names only this model's images and keeps their
-                # buffers alive, so nothing another model (or the garbage collector) does to the registry can invalidate it
-                self.wtable = ops.freeze_weight_table(self.params)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.out = body()
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(max(1, warmup)):                    # lazily-created state (caches, job table, rings) settles here
+                    out = body()
+                    if reducer is not None:
+                        reducer.finalize()
+                del out
+                torch.cuda.synchronize(dev)
+                for p in self.params:
+                    p.grad = None
+                ops.reset_capture_pools()
+                if refresh_weights:
+                    # the captured refresh replays against a table of its own: it names only this model's images and keeps their
+                    # buffers alive, so nothing another model (or the garbage collector) does to the registry can invalidate it
+                    self.wtable = ops.freeze_weight_table(self.params)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.out = body()
+        except BaseException:
+            # a failed warm-up / capture must not leave the process in capture configuration: the reducer back to
+            # immediate mode, the section / weight-gradient stream policies back to what they were
+            if reducer is not None:
+                reducer.deferred = False
+            ops.SECTIONS_DISTINCT = prev_distinct
+            raise
+        finally:
+            ops.WGRAD_STREAM = prev_wgrad
         torch.cuda.current_stream(dev).wait_stream(self.stream)
-        ops.WGRAD_STREAM = prev_wgrad
         self.grads = {p: p.grad for p in self.params if p.grad is not None}      # static tensors the replays write
 
     def replay(self):
@@ -229,11 +238,14 @@ class Trainer:
                 video = self.video_loader.batch()[0] if is_cycle else None
                 loss, pred = self.train_step(imgs, masks, video)
             self.scheduler.step()
+            # the epoch's Dice sums its counters over ranks: a collective, so EVERY rank computes it (only rank 0 prints)
+            dice = {v: self._calculate_overlap_metrics(masks[v], pred[v].detach())[1] for v in self.test_view}
             if self.print_val:
-                dice = {v: self._calculate_overlap_metrics(masks[v], pred[v].detach())[1] for v in self.test_view}
                 print(f"epoch {epoch}: loss {float(loss):.2f} dice {dice}")
                 if self.config["train"].get("validate_every_epoch", True):
-                    self.validation_and_test(net_root=None, is_fuse=True, raw_data=True)      # main.py:274
+                    # main.py:259-274: validation runs on the printing rank alone, over every clip of the splits, with NO collective
+                    # (the other ranks have already moved on to the next epoch's gradient all-reduces and wait there)
+                    self.validation_and_test(net_root=None, is_fuse=True, raw_data=True, reduce=False)
             self.save(epoch)
 
     @torch.no_grad()
@@ -288,14 +300,16 @@ class Trainer:
 
     @torch.no_grad()
     def validation_and_test(self, net_root: str = None, is_fuse: bool = True, raw_data: bool = True, infos: dict = None,
-                            val_list=("0_0", "0_2"), test_list=("0_1", "0_3", "0_4", "0_5", "0_6", "0_7", "0_8", "0_9"), first_scored: int = 50):
+                            val_list=("0_0", "0_2"), test_list=("0_1", "0_3", "0_4", "0_5", "0_6", "0_7", "0_8", "0_9"), first_scored: int = 50,
+                            reduce: bool = True):
         """main.py:279-415.  Two splits of the test infos -- 'Inner-val' (ids 0_0, 0_2) and 'Inner-test' (the other eight) --
         evaluated clip by clip (batch 1, all frames of the clip as the model's batch, main.py:361-365): per view the BCE-sum loss,
         pixel accuracy / Dice / precision / specificity / recall over ALL frames of the split and the per-part Dice
         (main.py:385-407).  net_root None (the call at the end of every training epoch, main.py:274): the current weights, returns
         the validation Dice averaged over views (main.py:409-410).  With net_root: every checkpoint net_%05d.pth found there is
         loaded and scored, and the best validation epoch from `first_scored` on is reported (main.py:412-415: epochs 50+).
-        `infos`: the reference loads ./infos/test_infos.npy (NIfTI paths, not shipped); default = synthetic volumes with the same ids."""
+        `infos`: the reference loads ./infos/test_infos.npy (NIfTI paths, not shipped); default = synthetic volumes with the same ids.
+        reduce: sum the overlap counters over ranks (every rank must then make this call); False for a call made by one rank alone."""
         from .data import SegPAHDataset, synthetic_infos, part_overlap_counts
         clip = 40 if raw_data else int(self.config["train"].get("clip_length", 40))                       # main.py:307-311
         if infos is None:
@@ -323,7 +337,8 @@ class Trainer:
                         loss4view[v] += float(ops.bce_with_logits_sum(pred[v], masks[v]))
                 res = {}
                 for v in self.test_view:
-                    per_part = all_reduce_counts(counts[v])
+                    # reduce=False: this rank scored every clip itself (the per-epoch call from train(), rank 0 only): no collective
+                    per_part = all_reduce_counts(counts[v]) if reduce else counts[v]
                     res[v] = {"metrics": ops.overlap_metrics_from_counts(per_part.sum(dim=0)), "loss": loss4view[v],
                               "part_dice": [ops.overlap_metrics_from_counts(per_part[c])[1] for c in range(5)]}
                     if self.print_val:

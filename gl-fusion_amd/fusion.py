@@ -220,6 +220,8 @@ class TpaviFn(Function):
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)
+        if not split_mode():
+            sp = max(sp, min((rows + 511) // 512, 65535))          # (as for the projections' weight gradient below)
         dzW = (zeros if tn_needs_zero(sp) else torch.empty)(c, ci, **f32)
         am_dwz, am_q = amax_of(dwz), amax_of(qkv)
         ok = tn_presplit_ok(c, ci, c, ci)
@@ -293,6 +295,11 @@ class TpaviFn(Function):
 
         # the three projections as one: qkv = x Wcat^T + bcat
         sp = _tn_split(rows, c3, c, 1)
+        if not split_mode():
+            # exact fp32: this weight gradient's terms cancel to ~1e-3 of their size, and the exact TN kernel adds its K-tile sums in
+            # ONE fp32 chain per slice -- slices of at most 512 rows (16 K-tiles; the second stage adds the slabs in double) keep the
+            # strict-precision leg at least as accurate as the split-fp16 one (3e-3 -> 1.5e-3 on the smoke fixture)
+            sp = max(sp, min((rows + 511) // 512, 65535))
         dWcat = (zeros if tn_needs_zero(sp) else torch.empty)(c3, c, **f32)
         am_dq = amax_of(dqkv)
         ok = tn_presplit_ok(c3, c, c3, c)

@@ -73,6 +73,39 @@ def _worker(rank, world, port, tmp):
     bce(model(xs[lo:hi]), ts[lo:hi]).backward()
     red.finalize()
     torch.save({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, os.path.join(tmp, f"s{rank}.pt"))
+    # finalize() has waited for every collective it launched (on a GPU: the stream the optimizer runs on waits for them) and re-armed
+    assert all(b.work is None and b.pending == len(b.params) and not any(b.fired) for b in red.buckets)
+    want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # an eager step that DOES use `spare` leaves reduced values in its bucket slices; the deferred steps that
+    # follow do not use it -- its slices must contribute zeros (not the stale sums, re-reduced in place on every replay), and going
+    # back to eager mode afterwards must work from clean per-step state
+    for p in model.parameters():
+        p.grad = None
+    model.spare(torch.ones(1, 8, 2, 2)).sum().backward()
+    red.finalize()
+    assert model.spare.weight.grad is not None and float(model.spare.weight.grad.abs().sum()) > 0
+    wb, wi = red._where[model.spare.weight]
+    red.deferred = True
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        bce(model(xs[lo:hi]), ts[lo:hi]).backward()
+        red.finalize()
+        off = wb.offsets[wi]
+        assert float(wb.flat[off:off + model.spare.weight.numel()].abs().sum()) == 0.0
+        assert model.spare.weight.grad is None
+        for n, p in model.named_parameters():
+            if n in want:
+                assert torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-6), ("deferred", n)
+    red.deferred = False
+    for p in model.parameters():
+        p.grad = None
+    bce(model(xs[lo:hi]), ts[lo:hi]).backward()
+    red.finalize()
+    for n, p in model.named_parameters():
+        if n in want:
+            assert torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-6), ("eager after deferred", n)
+    assert model.spare.weight.grad is None
     dist.destroy_process_group()
 
 

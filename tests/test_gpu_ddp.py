@@ -209,3 +209,33 @@ def test_bench_self_launch_two_ranks():
         assert ("hipGraph" in line["launch"]) == (graph == "1")
         if graph == "1":
             assert line["config"]["allreduce_ms_per_step"] is not None
+
+
+def _trainer_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from glfusion_amd.engine import Trainer
+    cfg = {"train": {"batch_size": 2, "num_epochs": 2, "clip_length": 8, "view_num": ["1"], "test_view": ["1"], "dense_cyc": False,
+                     "save_dir": os.path.join(tmp, f"ckpt{rank}"), "iters_per_epoch": 1, "global_rank": rank, "validate_every_epoch": True},
+           "net": {"opt": {"opt_name": "Adam", "lr": 1e-5, "params": (0.9, 0.999), "weight_decay": 1e-5}}}
+    t = Trainer(cfg)
+    assert t.print_val == (rank == 0)
+    t.train(is_backbone=False, is_cycle=False)                # two epochs: the second one's all-reduces follow rank 0's validation
+    torch.cuda.synchronize()
+    w = t.model.classifier["1"][4].weight.detach().float().cpu()
+    torch.save({"w": w, "val": getattr(t, "validation_report", None) is not None}, os.path.join(tmp, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_with_per_epoch_validation(tmp_path):
+    """Trainer.train() with validate_every_epoch=True on two ranks.  The per-epoch Dice is a collective every
+    rank joins; the validation pass runs on the printing rank alone WITHOUT collectives (main.py:259-274) -- before the fix rank 0
+    entered all-reduces no other rank joined and the next epoch's gradient buckets were paired with them.  Two epochs complete,
+    only rank 0 validates, and the replicas end with identical parameters."""
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"t{i}.pt") for i in range(world)]
+    assert r[0]["val"] and not r[1]["val"]
+    assert torch.equal(r[0]["w"], r[1]["w"])

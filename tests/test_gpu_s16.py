@@ -504,3 +504,56 @@ def test_s16_e2e_train_step_vs_reference_kinkfree_fixture(golden_dir):
         if k == "centerness":
             continue
         assert rel <= 1.0 and cos >= 0.5 and 0.35 <= proj <= 1.5, (k, rel, cos, proj)
+
+
+def test_s16_config5_full_clip_T32_on_one_gpu():
+    """BASELINE.json configs[4] ("bf16 ... long-sequence cross-view attention at the HBM limit") at its FULL per-GPU size under
+    16-bit storage: one clip of 5 views x 32 frames x 224 x 224 (L = 15 680 positions per frame).  Size-independent checks, as in
+    tests/test_gpu_model.py::test_config5_full_clip_T32_on_one_gpu: (a) the eval forward over 32 frames equals two 16-frame forwards
+    (frames are independent under running statistics: the bf16 fusion features match bit for bit, the fp32 logits -- the 5-channel
+    output conv runs on the exact-fp32 kernels, whose tiling depends on the row count -- to 1e-5) and the SUM loss adds up; (b) the train step is finite and every live parameter gets a finite, non-zero-norm gradient; (c) the step's peak
+    allocation stays under 130 GB (fp32 storage: 230 GB with retained operand images, 183 GB without)."""
+    from glfusion_amd import ops
+    from glfusion_amd.models import Global_and_Local
+    views, T = ["1", "2", "3", "4", "5"], 32
+    model = Global_and_Local(views)
+    orc.closed_form_fill(model, salt=4)
+    model = model.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    imgs = {v: torch.rand(T, 1, 224, 224, device=DEV, generator=g) for v in views}
+    tgts = {v: (torch.rand(T, 5, 224, 224, device=DEV, generator=g) < 0.3).float() for v in views}
+    try:
+        model.eval()
+        with torch.no_grad():
+            full, _, full_g, _ = model(imgs)
+            l_full = sum(float(ops.bce_with_logits_sum(full[v], tgts[v])) for v in views)
+            l_halves = 0.0
+            for lo, hi in ((0, 16), (16, 32)):
+                part, _, part_g, _ = model({v: t[lo:hi] for v, t in imgs.items()})
+                for v in views:
+                    assert torch.equal(part_g[v], full_g[v][lo:hi]), (v, lo)
+                    assert float((part[v] - full[v][lo:hi]).abs().max()) <= 1e-5 * max(1.0, float(full[v].abs().max())), (v, lo)
+                    l_halves += float(ops.bce_with_logits_sum(part[v], tgts[v][lo:hi]))
+            assert abs(l_full - l_halves) <= 1e-6 * abs(l_full)
+            del full, part, full_g, part_g
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        model.train()
+        pred = model(imgs)[0]
+        loss = sum(ops.bce_with_logits_sum(pred[v], tgts[v]) for v in views)
+        loss.backward()
+        torch.cuda.synchronize()
+        lv = float(loss.detach())
+        assert lv == lv and abs(lv) < 1e13
+        live = {n for n, p in model.named_parameters() if p.grad is not None}
+        assert len(live) > 1000 and not any(n.startswith("network.") or ".align_channel." in n for n in live)
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                assert bool(torch.isfinite(p.grad).all()), n
+        assert float(model.layer4["3"][2].conv3.weight.grad.abs().sum()) > 0 and float(model.global_attn.theta.weight.grad.abs().sum()) > 0
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        print(f"s16 config 5, one clip (5 views x 32 x 224^2) on one GPU: loss {lv:.1f}, peak allocation {peak:.0f} GB")
+        assert peak < 130
+    finally:
+        del model, imgs, tgts
+        torch.cuda.empty_cache()
