@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default since the eager step became the faster one) time the eagerly issued step")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short measurement of the launch mode that was not timed")
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
+    ap.add_argument("--fusion-block-only", action="store_true", help="run only the fusion-block measurement of --precision and print it (the "
+                    "command the rocprofv3 --pmc MFMA-busy pass of profiles/ubench/r04_profiles.sh wraps)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the 16-bit-storage leg (BASELINE.json configs[2] as stated: bf16 storage)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16", "bf16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -468,7 +470,62 @@ def main():
                                                                  "on real data)"}
         return roofline
 
+    def fusion_block_leg(precision: str):
+        """north_star: '>= 40 % MFMA utilisation on the fusion block'.  ONE TPAVIModule (ours.py:845-917, dot mode) forward + backward
+        at the C2 shape (N = 64 frames, L = 3 x 28 x 28 positions, C = 2048), alone on the GPU, timed with events over 5 repetitions
+        after 2: ms, executed MFMA TFLOP/s (3 / 1 instruction FLOPs per algorithmic FLOP under f16x3 / bf16) and its fraction of the
+        2.5 PF dense peak.  SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles cannot be read in-process: `mfma_busy` comes from the stamped
+        rocprofv3 --pmc pass over this same function (profiles/ubench/r04_profiles.sh), refused when stale."""
+        ops.set_precision(precision)
+        n, v, hw, c, ci = n_frames, len(VIEWS), 28, 2048, 1024
+        L = v * hw * hw
+        rows = n * L
+        g = torch.Generator(device=dev).manual_seed(99)
+        x = torch.randn(n, v, hw, hw, c, device=dev, generator=g).to(ops.act_dtype()).requires_grad_(True)
+        dz = torch.randn(n, v, hw, hw, c, device=dev, generator=g).to(ops.act_dtype())
+        mod = model.global_attn
+
+        def once():
+            x.grad = None
+            z = mod.forward_nvhwc(x)
+            z.backward(dz)
+        for _ in range(2):
+            once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            once()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        unit = 2.0 * rows * c * ci                          # one [rows, C] x [C, Ci] contraction
+        att = 2.0 * n * L * ci * ci                         # one per-frame [L, Ci] x [Ci, Ci] contraction
+        flops = (3 * unit + unit + 2 * att) + (2 * unit + 4 * att + 6 * unit)      # forward + backward, re-associated dot attention
+        nm = {"f32": 1, "bf16x6": 6, "f16x3": 3, "f16": 1, "bf16": 1}[precision]
+        peak = FP32_MFMA_PEAK_TFLOPS if precision == "f32" else BF16_MFMA_PEAK_TFLOPS
+        busy = None
+        try:
+            meta = json.load(open(os.path.join(ROOT, "profiles", f"r04_fusion_block_{precision}_mfma_busy.meta.json")))
+            if meta.get("kernel_sources_sha256") == kernel_sources_sha256():
+                busy = json.load(open(os.path.join(ROOT, "profiles", f"r04_fusion_block_{precision}_mfma_busy.json")))
+            else:
+                busy = {"value": None, "reason": "stale profile (kernel sources changed since it was collected)"}
+        except (OSError, ValueError):
+            busy = {"value": None, "reason": f"no stamped profile profiles/r04_fusion_block_{precision}_mfma_busy.json"}
+        for p_ in mod.parameters():
+            p_.grad = None
+        del x, dz
+        return {"precision": precision, "ms": round(ms, 3), "algorithmic_tflop": round(flops / 1e12, 3),
+                "executed_mfma_tflops": round(nm * flops / ms / 1e9, 1), "fp32_equiv_tflops": round(flops / ms / 1e9, 1),
+                "frac": round(nm * flops / ms / 1e9 / peak, 4), "peak": peak, "mfma_busy": busy,
+                "what": "one TPAVIModule (dot mode) forward + backward, N=64 frames x L=2352 positions x C=2048, alone on the GPU"}
+
+    if args.fusion_block_only:
+        print(json.dumps(fusion_block_leg(args.precision)))
+        return
     main_leg = run_leg(args.precision)
+    fusion_main = fusion_block_leg(args.precision) if world == 1 else None
     # second leg with the SAME --steps / --warmup: the strictly-fp32 step (v_mfma_f32_32x32x2_f32 everywhere), its own roofline
     exact_leg = run_leg("f32") if (args.precision != "f32" and not args.no_exact_f32) else None
     # third leg, same --steps / --warmup: BASELINE.json configs[2] (16-bit MFMA arithmetic): fp16 operands, one MFMA per product
@@ -476,6 +533,7 @@ def main():
     # fourth leg: BASELINE.json configs[2] AS STATED -- bf16 storage of activations / saved tensors / activation gradients (ops16)
     s16_leg = run_leg("bf16") if (args.precision == "f16x3" and not args.no_bf16) else None
     s16_peak_mem = round(torch.cuda.max_memory_allocated() / 2**30, 2) if s16_leg is not None else None
+    fusion_s16 = fusion_block_leg("bf16") if (s16_leg is not None and world == 1) else None
     ops.set_precision(args.precision)
 
     # secondary figure (outside the metric, which excludes the optimizer): the fused Adam step over
@@ -571,6 +629,8 @@ def main():
             "loss": main_leg["loss"], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
             "roofline": roofline_of(main_leg),
         }
+        if fusion_main is not None:
+            out["fusion_block"] = fusion_main
         if exact_leg is not None:
             out["exact_f32"] = {"value": round(args.clips * world * args.steps / exact_leg["dt"], 4), "unit": "clips/s",
                                 "ms_per_step": round(exact_leg["dt"] / args.steps * 1e3, 2), "steps": args.steps, "warmup": args.warmup,
@@ -593,7 +653,7 @@ def main():
                                            "activation gradient stored as bf16 in HBM (glfusion_amd.ops16; csrc/gemm_s16.hip, csrc/s16_ops.hip), ONE "
                                            "v_mfma_f32_32x32x16_bf16 per product on operands staged global -> LDS by LDS-DMA; NOT fp32-equivalent and "
                                            "never the headline (tolerances: tests/test_gpu_s16.py)",
-                                   "roofline": roofline_of(s16_leg)}
+                                   "roofline": roofline_of(s16_leg), "fusion_block": fusion_s16}
         out["optimizer_step"] = optimizer_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

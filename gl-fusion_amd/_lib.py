@@ -46,6 +46,12 @@ class AttnParams(C.Structure):
                 ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldy", C.c_int64), ("lddy", C.c_int64), ("ldd", C.c_int64)]
 
 
+class TpaviParams(C.Structure):
+    """Mirror of glf_tpavi_params (include/glfusion.h)."""
+    _fields_ = [("n", C.c_int32), ("L", C.c_int32), ("c", C.c_int32), ("ci", C.c_int32), ("training", C.c_int32),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("ln_eps", C.c_float)]
+
+
 class ConvParams(C.Structure):
     """Mirror of glf_conv_params (include/glfusion.h)."""
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32),
@@ -84,6 +90,8 @@ def _ctype(decl: str):
         return C.POINTER(GemmParams)
     if "glf_attn_params" in decl:
         return C.POINTER(AttnParams)
+    if "glf_tpavi_params" in decl:
+        return C.POINTER(TpaviParams)
     if "glf_conv_params" in decl:
         return C.POINTER(ConvParams)
     if "glf_conv_plan" in decl:

@@ -202,6 +202,84 @@ __global__ __launch_bounds__(RT) void bnbwd_reduce_kernel(OpBnBwd op, int rows, 
     }
 }
 
+// ---- the same reduction WITHOUT a second stage (round 4): per-thread fp32 partial sums over its <= ~16-64 rows (four rows' loads
+// in flight at a time), the workgroup's row lanes folded in double through LDS, then ONE f64 atomic per column, statistic and
+// workgroup into a zero-filled [2][c] buffer (consecutive threads own consecutive columns: a wave's atomics cover 512 contiguous
+// bytes), and one atomicMax per column for the two maxima the packed-gradient bound needs.  bn_bwd_apply_kernel finishes the sums
+// in its prologue: two launches per BatchNorm backward instead of three (the finalize kernels were 221 launches of ~14 us per step).
+__host__ __device__ inline int fused_slices(int rows, int c) {
+    const int c4 = c > 4 ? c / 4 : 1;
+    const int tpr = c4 < RT ? c4 : RT;
+    const int rpp = RT / tpr;
+    int s = (rows + 16 * rpp - 1) / (16 * rpp);
+    const int cblocks = (c4 + tpr - 1) / tpr;
+    int cap = 1024 / cblocks;
+    if (cap < 1) cap = 1;
+    return s < 1 ? 1 : (s > cap ? cap : s);
+}
+__global__ __launch_bounds__(RT) void bnbwd_reduce_atomic_kernel(OpBnBwd op, int rows, int c, int slices, double* __restrict__ sums,
+                                                                 float* __restrict__ cmax) {
+    __shared__ float sh[RT * 8];                  // [statistic][row lane][column] for the sums, reused for the maxima
+    const int tid = threadIdx.x;
+    const int c4 = c >> 2;
+    const int tpr = c4 < RT ? c4 : RT;
+    const int rpp = RT / tpr;
+    const int ct = tid % tpr, rl = tid / tpr;
+    const int slice = blockIdx.x;
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = slice * per, r1 = min(rows, r0 + per);
+    for (int cb = blockIdx.y * tpr; cb < c4; cb += gridDim.y * tpr) {
+        const int cc = cb + ct;
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, mg = sa, mx = sa;
+        if (cc < c4 && rl < rpp) {
+            const float4 mu = *reinterpret_cast<const float4*>(op.mean + cc * 4);
+            const float4 is = *reinterpret_cast<const float4*>(op.invstd + cc * 4);
+            auto acc1 = [&](int r) __attribute__((always_inline)) {
+                float4 a, b;
+                op(r, cc * 4, a, b);
+                sa.x += a.x; sa.y += a.y; sa.z += a.z; sa.w += a.w;
+                sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
+                if (cmax) {
+                    const float4 xx = *reinterpret_cast<const float4*>(op.x + (long long)r * op.ldx + cc * 4);   // (the load op() made: CSE'd)
+                    mg.x = fmaxf(mg.x, fabsf(a.x)); mg.y = fmaxf(mg.y, fabsf(a.y)); mg.z = fmaxf(mg.z, fabsf(a.z)); mg.w = fmaxf(mg.w, fabsf(a.w));
+                    mx.x = fmaxf(mx.x, fabsf((xx.x - mu.x) * is.x)); mx.y = fmaxf(mx.y, fabsf((xx.y - mu.y) * is.y));
+                    mx.z = fmaxf(mx.z, fabsf((xx.z - mu.z) * is.z)); mx.w = fmaxf(mx.w, fabsf((xx.w - mu.w) * is.w));
+                }
+            };
+            int r = r0 + rl;
+            for (; r + 3 * rpp < r1; r += 4 * rpp) { acc1(r); acc1(r + rpp); acc1(r + 2 * rpp); acc1(r + 3 * rpp); }
+            for (; r < r1; r += rpp) acc1(r);
+        }
+        const int ncol = tpr * 4;
+        for (int pass = 0; pass < (cmax ? 2 : 1); ++pass) {
+            if (rl < rpp) {
+                const float4 u = pass == 0 ? sa : mg, v = pass == 0 ? sb : mx;
+                float* d0 = sh + (0 * rpp + rl) * ncol + ct * 4;
+                float* d1 = sh + (1 * rpp + rl) * ncol + ct * 4;
+                d0[0] = u.x; d0[1] = u.y; d0[2] = u.z; d0[3] = u.w;
+                d1[0] = v.x; d1[1] = v.y; d1[2] = v.z; d1[3] = v.w;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 2 * ncol; idx += RT) {
+                const int st = idx / ncol, col = idx - st * ncol;
+                const int gc = cb * 4 + col;
+                if (gc < c) {
+                    if (pass == 0) {
+                        double d = 0;
+                        for (int q = 0; q < rpp; ++q) d += sh[(st * rpp + q) * ncol + col];
+                        atomicAdd(sums + st * c + gc, d);
+                    } else {
+                        float m = 0.f;
+                        for (int q = 0; q < rpp; ++q) m = fmaxf(m, sh[(st * rpp + q) * ncol + col]);
+                        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(cmax + st * c + gc), __float_as_uint(m));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // stage 2: fold the per-slice partials.  One workgroup = 16 channels x 16 slice lanes (a serial loop over
 // up to 1024 slices per channel on a single thread was 13% of the whole step in the first profile).
 constexpr int FIN_CH = 16, FIN_LANES = 16;
@@ -442,11 +520,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, int lddx, float* __restrict__ dres, int lddres,
                                                            long long total4, int c4, int relu, int training, float inv_n,
                                                            float* __restrict__ amax_out, int packed, const unsigned char* __restrict__ mask,
-                                                           const float* __restrict__ dy2, int lddy2) {
+                                                           const float* __restrict__ dy2, int lddy2, const double* __restrict__ fsums,
+                                                           const float* __restrict__ fmax, float* __restrict__ out_dbeta, float* __restrict__ out_dgamma,
+                                                           int c) {
     // packed != 0: dx is written as the packed pre-split fp16 image (glf_split_f16_packed's format) scaled by *amax_out, which
     // then holds an upper bound of max |dx| computed by bnbwd_finalize (not a by-product of this kernel)
+    // fsums != null (fused form): the reduction left UNFINISHED sums (doubles [2][c]) and, for the packed form, per-channel maxima
+    // (fmax [2][c]); every workgroup finishes them in LDS -- sum_dy / sum_dyx then point into LDS -- workgroup 0 writes dbeta /
+    // dgamma, and the packed form's bound (bnbwd_finalize's expression) is derived by every workgroup before it writes anything
+    extern __shared__ __attribute__((aligned(16))) float s_fin[];        // [2][c]
+    __shared__ float s_bound[4];
+    float bound_local = 0.f;
+    if (fsums) {
+        for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+            const float a = (float)fsums[ch], b = (float)fsums[c + ch];
+            s_fin[ch] = a; s_fin[c + ch] = b;
+            if (blockIdx.x == 0) { if (out_dbeta) out_dbeta[ch] = a; if (out_dgamma) out_dgamma[ch] = b; }
+            if (packed) {
+                const float kk = fabsf(k.gamma[ch] * k.invstd[ch]);
+                const float bb = 1.0001f * kk * (training ? fmax[ch] + inv_n * (fabsf(a) + fmax[c + ch] * fabsf(b)) : fmax[ch]);
+                if (bb < 3.0e38f) bound_local = fmaxf(bound_local, bb);
+            }
+        }
+        if (packed) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bound_local = fmaxf(bound_local, __shfl_xor(bound_local, o, 64));
+            if ((threadIdx.x & 63) == 0) s_bound[threadIdx.x >> 6] = bound_local;
+        }
+        __syncthreads();
+        sum_dy = s_fin; sum_dyx = s_fin + c;
+    }
     float am = 0.f, sc = 1.f, sc_inv = 1.f;
-    if (packed) pow2_scale(amax_out, sc, sc_inv);
+    if (packed && fsums) {
+        float bnd = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3]));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *amax_out = bnd;
+        pow2_scale(&bnd, sc, sc_inv);
+    } else if (packed) pow2_scale(amax_out, sc, sc_inv);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
@@ -709,9 +818,9 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                           int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
-                          const uint8_t* relu_mask, const float* dy2, int lddy2, glf_stream_t s) {
+                          const uint8_t* relu_mask, const float* dy2, int lddy2, double* fused_sums, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
-    GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && workspace, GLF_ERR_NULL, "bn_bwd: null argument");
+    GLF_REQUIRE(dy && x && mean && invstd && gamma && dx && (workspace || fused_sums), GLF_ERR_NULL, "bn_bwd: null argument");
     if (relu_mask) y = nullptr;
     GLF_REQUIRE(!packed_dx || amax_out, GLF_ERR_NULL, "bn_bwd: packed_dx needs amax_out (a zeroed device float that receives the bound the image is scaled with)");
     GLF_REQUIRE(!relu || y || beta || relu_mask, GLF_ERR_NULL, "bn_bwd: relu != 0 needs relu_mask, y (the forward output) or beta (to recompute its sign from x)");
@@ -720,8 +829,23 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     if (relu && y) { REQ_AL(y, "y"); REQ_LD(ldy, "ldy"); }
     if (dres) { REQ_AL(dres, "dres"); REQ_LD(lddres, "lddres"); }
     if (dy2) { REQ_AL(dy2, "dy2"); REQ_LD(lddy2, "lddy2"); }
-    const int slices = n_slices_c(rows, c);
     const OpBnBwd op{dy, lddy, x, ldx, y, ldy, mean, invstd, gamma, beta, relu, relu_mask, c / 4, dy2, lddy2};
+    const long long total4f = (long long)rows * (c / 4);
+    if (fused_sums && c <= APPLY_MAX_C) {
+        // two launches: reduction with atomics into the caller's ZERO-FILLED buffer (2 c doubles, then 2 c floats of maxima), apply
+        float* fmax = reinterpret_cast<float*>(fused_sums + (size_t)2 * c);
+        const int fs = fused_slices(rows, c);
+        const int c4 = c / 4, tpr = c4 < RT ? c4 : RT;
+        hipLaunchKernelGGL(bnbwd_reduce_atomic_kernel, dim3(fs, (c4 + tpr - 1) / tpr), dim3(RT), 0, glf::S(s), op, rows, c, fs, fused_sums,
+                           packed_dx ? fmax : (float*)nullptr);
+        if (int rc = glf::check_launch("bn_bwd_reduce(fused)")) return rc;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4f, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s), dy, lddy, x, ldx, y, ldy,
+                           Coef{mean, invstd, gamma, beta}, (const float*)nullptr, (const float*)nullptr, dx, lddx, dres, lddres, total4f, c / 4, relu, training,
+                           1.0f / (float)rows, amax_out, packed_dx, relu_mask, dy2, lddy2, fused_sums, fmax, dbeta, dgamma, c);
+        return glf::check_launch("bn_bwd_apply(fused)");
+    }
+    GLF_REQUIRE(workspace, GLF_ERR_NULL, "bn_bwd: the three-launch form needs the workspace");
+    const int slices = n_slices_c(rows, c);
     // per-channel sums live behind the partials in the workspace (as floats) when the caller does not want them
     float* sums = reinterpret_cast<float*>(workspace + (size_t)2 * slices * c);
     float* s_dy = dbeta ? dbeta : sums;
@@ -741,7 +865,8 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
     const long long total4 = (long long)rows * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4, 256)), dim3(256), 0, glf::S(s), dy, lddy, x, ldx, y, ldy,
                        Coef{mean, invstd, gamma, beta}, s_dy, s_dyx, dx, lddx, dres, lddres, total4, c / 4, relu, training,
-                       1.0f / (float)rows, amax_out, packed_dx, relu_mask, dy2, lddy2);
+                       1.0f / (float)rows, amax_out, packed_dx, relu_mask, dy2, lddy2, (const double*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, c);
     return glf::check_launch("bn_bwd_apply");
 }
 

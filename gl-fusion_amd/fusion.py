@@ -215,8 +215,11 @@ class TpaviFn(Function):
         dbn_g = torch.empty(c, **f32)
         dbn_b = torch.empty(c, **f32)
         dwz_pk = bool(training and split and PACKED_TPAVI and am_dwz_slot is not None and nt_presplit_ok(c, c, c) and tn_presplit_ok(c, ci, c, ci))
+        from .ops import FUSED_BN_BWD, bnbwd_slot
+        fused = bnbwd_slot(c, dev) if (FUSED_BN_BWD and c <= 4096) else None
         check(lib.glf_bn_bwd(_p(du), c, _p(wz), c, None, c, _p(mean), _p(invstd), _p(bn_g), None, _p(dwz), c, None, c,
-                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), _p(_ws(rows, c, dev)), _p(am_dwz_slot), int(dwz_pk), None, None, 0, _stream()), "bn_bwd")
+                             _p(dbn_g), _p(dbn_b), rows, c, 0, int(training), None if fused is not None else _p(_ws(rows, c, dev)), _p(am_dwz_slot),
+                             int(dwz_pk), None, None, 0, _p(fused), _stream()), "bn_bwd")
         set_amax(dwz, am_dwz_slot)
         # W_z: w = y zW^T + b
         sp = _tn_split(rows, c, ci, 1)

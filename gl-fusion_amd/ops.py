@@ -479,6 +479,15 @@ def stats_slot(c: int, dev) -> torch.Tensor:
     return pool[0][i:i + need].view(2, c)
 
 
+def bnbwd_slot(c: int, dev) -> torch.Tensor:
+    """Zeroed scratch of glf_bn_bwd's two-launch form (fused_sums): 2 c doubles of sums followed by 2 c floats of maxima, carved out of
+    the pooled, bulk-zeroed statistics buffer (stats_slot)."""
+    return stats_slot((3 * c + 1) // 2, dev).view(-1)
+
+
+FUSED_BN_BWD = os.environ.get("GLF_FUSED_BN_BWD", "1") != "0"      # BatchNorm backward in two launches (atomics) instead of three
+
+
 _colmax_pool: dict = {}
 
 
@@ -1345,7 +1354,9 @@ class BatchNormActFn(Function):
         am = shared if shared is not None else amax_slot(dev)
         packed = packed and am is not None
         # relu + residual: the backward needs the sign of the forward output -- kept as one byte per four channels instead of y
-        need_mask = relu and residual is not None and torch.is_grad_enabled() and RELU_MASK_BYTES
+        # (grad mode is always OFF inside Function.forward: before round 4 this read torch.is_grad_enabled() and the sign bytes were
+        # never produced -- the backward fell back to re-reading y; what says that a backward may follow is needs_input_grad)
+        need_mask = relu and residual is not None and any(ctx.needs_input_grad[:4]) and RELU_MASK_BYTES
         mask = torch.empty(rows * (c // 4), dtype=torch.uint8, device=dev) if need_mask else None
         if fused_stats:
             check(lib.glf_bn_apply_from_sums(_p(x), c, _p(residual), c, _p(y), ldy, _p(sums), rows, c, eps, momentum, _p(gamma), _p(beta),
@@ -1390,9 +1401,10 @@ class BatchNormActFn(Function):
         # followed by a split pass
         packed = ctx.packed_grad and _PREC[0] >= 2 and am is not None and PACKED_GRADS
         mask = y if ctx.has_mask else None
+        fused = bnbwd_slot(c, dev) if (FUSED_BN_BWD and c <= 4096) else None
         check(lib.glf_bn_bwd(_p(dy), lddy, _p(x), c, None if ctx.has_mask else _p(y), ldy, _p(mean), _p(invstd), _p(gamma), _p(beta),
-                             _p(dx), c, _p(dres), c, _p(dgamma), _p(dbeta), rows, c, int(relu), int(training), _p(_ws(rows, c, dev)), _p(am),
-                             int(packed), _p(mask), _p(dy2), lddy2, _stream()), "bn_bwd")
+                             _p(dx), c, _p(dres), c, _p(dgamma), _p(dbeta), rows, c, int(relu), int(training),
+                             None if fused is not None else _p(_ws(rows, c, dev)), _p(am), int(packed), _p(mask), _p(dy2), lddy2, _p(fused), _stream()), "bn_bwd")
         set_amax(dx, am)
         if packed:
             dx._glf_packed_only = True

@@ -11,18 +11,21 @@ up-sampling, loss, metrics), per-channel statistics and every parameter / parame
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._lib import GemmParams, WJ_CVT_BF16, check, lib
+from ._lib import GemmParams, TpaviParams, WJ_CVT_BF16, check, lib
 from . import ops as _o
 
 BF = torch.bfloat16
 _p, _stream, _contig = _o._p, _o._stream, _o._contig
 DT_F32, DT_BF16 = 0, 1
+# block sequences through their single-call C entry points (glf_s16_tpavi_fwd / _bwd); 0 = composed from Python, the same launches
+BLOCK_CALLS = os.environ.get("GLF_BLOCK_CALLS", "1") != "0"
 
 
 def _chk16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
@@ -727,6 +730,26 @@ class Tpavi16Fn(Function):
         Wcat, bcat = _qkv_weights((th_w, ph_w, g_w, th_b, ph_b, g_b))
         c3 = 3 * ci
         qkv = torch.empty(rows, c3, dtype=BF, device=dev)
+        if BLOCK_CALLS and _o.PROFILER is None:
+            # the whole block as ONE C call (include/glfusion.h: glf_s16_tpavi_fwd); the composed sequence below is the same launches,
+            # kept for the per-contraction profiler hooks (tests/test_gpu_s16.py checks the two bit for bit)
+            tp = TpaviParams(n, L, c, ci, int(training), bn_eps, momentum, ln_eps)
+            attT = torch.empty(n, ci, ci, dtype=BF, device=dev)
+            y = torch.empty(rows, ci, dtype=BF, device=dev)
+            wz = torch.empty(rows, c, dtype=BF, device=dev)
+            z = torch.empty_like(x)
+            mean, invstd = torch.empty(c, **f32), torch.empty(c, **f32)
+            rmu, rrs = torch.empty(rows, **f32), torch.empty(rows, **f32)
+            nws = int(lib.glf_s16_tpavi_workspace_bytes(C.byref(tp), 0))
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            check(lib.glf_s16_tpavi_fwd(_p(x), _p(weight16(Wcat, Wcat, "w")), _p(bcat), _p(weight16(zW, wz_w, "w")), _p(wz_b), _p(bn_g), _p(bn_b),
+                                        _p(rmean), _p(rvar), _p(nbt), _p(ln_g), _p(ln_b), _p(z), _p(qkv), _p(attT), _p(y), _p(wz), _p(mean), _p(invstd),
+                                        _p(rmu), _p(rrs), C.byref(tp), _p(ws), nws, _stream()), "s16_tpavi_fwd")
+            ctx.save_for_backward(x, qkv, attT, y, wz, mean, invstd, rmu, rrs, Wcat, zW, bn_g, bn_b, ln_g)
+            ctx.cfg = (n, L, c, ci, training, tuple(th_w.shape), tuple(wz_w.shape))
+            ctx.owners = (wz_w,)
+            ctx.tp = tp
+            return z
         gemm16("nt", x, weight16(Wcat, Wcat, "w"), qkv, M=rows, N=c3, K=c, lda=c, ldb=c, ldc=c3, bias=bcat)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
         bq = L * c3
@@ -767,6 +790,22 @@ class Tpavi16Fn(Function):
         dz = _contig(dz)
         c3 = 3 * ci
         bq, bs = L * c3, L * ci
+        if BLOCK_CALLS and _o.PROFILER is None:
+            tp = TpaviParams(n, L, c, ci, int(training), 0.0, 0.0, 0.0)
+            dx = torch.empty(rows, c, dtype=BF, device=dev)
+            dWcat, dbcat = torch.empty(c3, c, **f32), torch.empty(c3, **f32)
+            dzW, dzb = torch.empty(c, ci, **f32), torch.empty(c, **f32)
+            dbn_g, dbn_b, dln_g, dln_b = (torch.empty(c, **f32) for _ in range(4))
+            nws = int(lib.glf_s16_tpavi_workspace_bytes(C.byref(tp), 1))
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            check(lib.glf_s16_tpavi_bwd(_p(dz), _p(x), _p(qkv), _p(attT), _p(y), _p(wz), _p(mean), _p(invstd), _p(rmu), _p(rrs),
+                                        _p(weight16(_o.weight_T(Wcat, Wcat), Wcat, "T2")), _p(weight16(_o.weight_T(zW, wz_o), wz_o, "T2")),
+                                        _p(bn_g), _p(bn_b), _p(ln_g), _p(dx), _p(dWcat), _p(dbcat), _p(dzW), _p(dzb), _p(dbn_g), _p(dbn_b),
+                                        _p(dln_g), _p(dln_b), C.byref(tp), _p(ws), nws, _stream()), "s16_tpavi_bwd")
+            grads_w = [dWcat[i * ci:(i + 1) * ci].reshape(pshape) for i in range(3)]
+            grads_b = [dbcat[i * ci:(i + 1) * ci] for i in range(3)]
+            return (dx.view_as(x), grads_w[0], grads_b[0], grads_w[1], grads_b[1], grads_w[2], grads_b[2], dzW.view(zshape), dzb,
+                    dbn_g, dbn_b, dln_g, dln_b, None, None, None, None, None, None, None, None)
         th, ph, g = qkv[:, 0:ci], qkv[:, ci:2 * ci], qkv[:, 2 * ci:]
         du = torch.empty(rows, c, dtype=BF, device=dev)
         dln_g = torch.empty(c, **f32)

@@ -380,6 +380,40 @@ int glf_s16_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64
 int glf_s16_transpose2d(const void* src, void* dst, int rows, int cols, int batch, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
+ * Single-call fusion block, 16-bit storage (SURVEY 8b rows tpavi_proj + tpavi_attn_dot +
+ * tpavi_out_bn_res_ln; TPAVIModule.forward, ours.py:845-917, mode 'dot' -- the shipped model).
+ * One call per direction enqueues the whole block on `stream`; the library allocates nothing:
+ * results, the tensors kept for backward and the workspace are caller-owned device buffers.
+ *   x, z, dz, dx   [n*L][C]    bf16   (n clips of L = V*h*w positions, channels-last)
+ *   w_qkv          [3 Ci][C]   bf16   theta | phi | g weights stacked;  b_qkv [3 Ci] fp32
+ *   w_z            [C][Ci]     bf16;  b_z [C] fp32
+ *   w_qkv_t / w_z_t             bf16   their transposes [C][3 Ci] / [Ci][C] (glf_s16_transpose2d)
+ *   qkv [n*L][3 Ci], att_t [n][Ci][Ci], y [n*L][Ci], wz [n*L][C]  bf16, bn_mean / bn_invstd [C],
+ *   row_mean / row_rstd [n*L] fp32: written by the forward, read by the backward.
+ *   dw_* / db_* / d*_gamma / d*_beta: fp32, torch parameter layouts.
+ * C, Ci multiples of 64, C <= 2048.  Workspace: glf_s16_tpavi_workspace_bytes(p, pass) bytes (pass 0 = forward,
+ * 1 = backward), 256-byte aligned, contents undefined on entry and exit.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n, L, c, ci;
+    int32_t training;            /* BatchNorm3d mode: batch statistics + running update (1) or running statistics (0) */
+    float bn_eps, bn_momentum, ln_eps;
+} glf_tpavi_params;
+size_t glf_sizeof_tpavi_params(void);
+size_t glf_s16_tpavi_workspace_bytes(const glf_tpavi_params* p, int pass);
+int glf_s16_tpavi_fwd(const void* x, const void* w_qkv, const float* b_qkv, const void* w_z, const float* b_z,
+                      const float* bn_gamma, const float* bn_beta, float* bn_running_mean, float* bn_running_var,
+                      int64_t* num_batches_tracked, const float* ln_gamma, const float* ln_beta, void* z,
+                      void* qkv, void* att_t, void* y, void* wz, float* bn_mean, float* bn_invstd, float* row_mean, float* row_rstd,
+                      const glf_tpavi_params* p, void* workspace, size_t workspace_bytes, glf_stream_t stream);
+int glf_s16_tpavi_bwd(const void* dz, const void* x, const void* qkv, const void* att_t, const void* y, const void* wz,
+                      const float* bn_mean, const float* bn_invstd, const float* row_mean, const float* row_rstd,
+                      const void* w_qkv_t, const void* w_z_t, const float* bn_gamma, const float* bn_beta, const float* ln_gamma,
+                      void* dx, float* dw_qkv, float* db_qkv, float* dw_z, float* db_z, float* dbn_gamma, float* dbn_beta,
+                      float* dln_gamma, float* dln_beta, const glf_tpavi_params* p, void* workspace, size_t workspace_bytes,
+                      glf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Stem (a2): Conv2d(1,64,7,stride 1,pad 2)+bias (models/_utils.py:192; used ours.py:1796).
  * x [N][H][W] (C=1), w [Cout][49], y [N][Ho][Wo][Cout] with Ho = H + 2*pad - 6.
  * ------------------------------------------------------------------------------------- */
@@ -468,7 +502,12 @@ int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* 
                const float* mean, const float* invstd, const float* gamma, const float* beta /* may be NULL with y */,
                float* dx, int lddx, float* dres, int lddres, float* dgamma, float* dbeta,
                int rows, int c, int relu, int training, double* workspace, float* amax_out, int packed_dx,
-               const uint8_t* relu_mask /* glf_bn_apply's sign bytes: replaces y */, const float* dy2, int lddy2, glf_stream_t s);
+               const uint8_t* relu_mask /* glf_bn_apply's sign bytes: replaces y */, const float* dy2, int lddy2,
+               double* fused_sums /* may be NULL.  Non-NULL (C <= 4096): 2 C doubles followed by 2 C floats, ALL ZERO on entry -- the
+                                     backward then takes TWO launches: the reduction meets in one f64 atomic per column and workgroup
+                                     there, the apply kernel finishes the sums itself (no finalize launch; `workspace` may be NULL).
+                                     dgamma / dbeta agree with the three-launch form to fp32 rounding, not bit for bit. */,
+               glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling / resampling / pointwise pieces of the path.

@@ -45,6 +45,8 @@ def test_gemm_params_struct_matches_header_layout():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     dll.glf_sizeof_gemm_params.restype = ctypes.c_size_t
     assert ctypes.sizeof(_lib.GemmParams) == dll.glf_sizeof_gemm_params()
+    dll.glf_sizeof_tpavi_params.restype = ctypes.c_size_t
+    assert ctypes.sizeof(_lib.TpaviParams) == dll.glf_sizeof_tpavi_params()
 
 
 def test_no_cpu_fallback():

@@ -355,6 +355,47 @@ def test_s16_tpavi_block_vs_oracle():
     _block_check(mod, ref, x, 5e-2, fwd=lambda m, t: m.forward_nvhwc(t), what="TPAVIModule(128)")
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_s16_tpavi_single_call_equals_composed_sequence(training, monkeypatch):
+    """glf_s16_tpavi_fwd / _bwd (one C call per direction, include/glfusion.h) against the same block composed from the
+    individual entry points by ops16.Tpavi16Fn: the same launches, so every output, buffer update and gradient bit for bit."""
+    from glfusion_amd import ops16
+    from glfusion_amd.models.ours import TPAVIModule
+    res = []
+    for block_calls in (True, False):
+        monkeypatch.setattr(ops16, "BLOCK_CALLS", block_calls)
+        mod = TPAVIModule(in_channels=256, mode="dot")
+        zero_mean_kinkfree_fill(mod, 52)
+        mod = mod.to(DEV).train(training)
+        x = torch.randn(2, 3, 20, 24, 256, generator=torch.Generator().manual_seed(512)).to(DEV).to(BF).requires_grad_(True)
+        z = mod.forward_nvhwc(x)
+        z.backward(torch.randn(z.shape, generator=torch.Generator().manual_seed(513)).to(DEV).to(BF))
+        torch.cuda.synchronize()
+        res.append((z.detach(), x.grad, {k: p.grad for k, p in mod.named_parameters()}, dict(mod.named_buffers())))
+    (z1, dx1, g1, b1), (z0, dx0, g0, b0) = res
+    assert torch.equal(z1, z0) and torch.equal(dx1, dx0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k
+
+
+def test_s16_tpavi_single_call_argument_checks():
+    import ctypes as C
+    from glfusion_amd._lib import TpaviParams, lib
+    tp = TpaviParams(2, 64, 128, 64, 1, 1e-5, 0.1, 1e-5)
+    assert lib.glf_s16_tpavi_workspace_bytes(C.byref(tp), 1) > lib.glf_s16_tpavi_workspace_bytes(C.byref(tp), 0) > 0
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    p = buf.data_ptr()
+    args_f = [p] * 21
+    assert lib.glf_s16_tpavi_fwd(*args_f, C.byref(tp), p, 16, None) == -3                 # GLF_ERR_WORKSPACE: too small
+    assert b"workspace" in lib.glf_last_error()
+    bad = TpaviParams(2, 64, 100, 64, 1, 1e-5, 0.1, 1e-5)
+    assert lib.glf_s16_tpavi_fwd(*args_f, C.byref(bad), p, 1 << 16, None) == -2           # GLF_ERR_UNSUPPORTED: C % 64
+    args_f[0] = None
+    assert lib.glf_s16_tpavi_fwd(*args_f, C.byref(tp), p, 1 << 16, None) == -5            # GLF_ERR_NULL
+
+
 # ----------------------------------------------------------------------------------------
 # the whole network vs the reference's fixtures
 # ----------------------------------------------------------------------------------------
