@@ -134,14 +134,18 @@ def measured_mfma_peak() -> float:
     """TFLOP/s of back-to-back fp16 MFMAs on random register operands on THIS box (glf_probe_mfma_f16), measured once per
     process: what the matrix cores sustain under their power limit when no byte moves."""
     if _MFMA_PEAK[0] is None:
-        from glfusion_amd._lib import lib, check
+        import ctypes
+        # a diagnostic library of its own (include/glfusion_diag.h), not part of libglfusion_hip.so
+        diag = ctypes.CDLL(os.path.join(ROOT, "gl-fusion_amd", "lib", "libglfusion_diag.so"))
+        diag.glf_probe_mfma_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
         blocks, iters = 1024, 60000
         out = torch.empty(blocks * 512, dtype=torch.float32, device="cuda")
         best = 0.0
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            check(lib.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 12345, torch.cuda.current_stream().cuda_stream), "probe_mfma_f16")
+            if diag.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 12345, torch.cuda.current_stream().cuda_stream) != 0:
+                raise RuntimeError("glf_probe_mfma_f16 failed")
             e1.record()
             e1.synchronize()
             best = max(best, blocks * 8 * iters * 4 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
@@ -218,6 +222,7 @@ def main():
     ap.add_argument("--clips", type=int, default=B, help="clips per GPU (default 4 = the headline config)")
     ap.add_argument("--fusion-block-only", action="store_true", help="run only the fusion-block measurement of --precision and print it (the "
                     "command the rocprofv3 --pmc MFMA-busy pass of profiles/ubench/r04_profiles.sh wraps)")
+    ap.add_argument("--no-fusion-block", action="store_true", help="skip the fusion-block measurements (profile passes: keeps the run to whole steps)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the 16-bit-storage leg (BASELINE.json configs[2] as stated: bf16 storage)")
     ap.add_argument("--precision", choices=["f32", "bf16x6", "f16x3", "f16", "bf16"], default=os.environ.get("GLF_PRECISION", "f16x3"),
                     help="contraction kernels: bf16x6 = split-bf16 (six bf16 MFMAs per fp32 product, fp32-equivalent results, "
@@ -525,7 +530,7 @@ def main():
         print(json.dumps(fusion_block_leg(args.precision)))
         return
     main_leg = run_leg(args.precision)
-    fusion_main = fusion_block_leg(args.precision) if world == 1 else None
+    fusion_main = fusion_block_leg(args.precision) if (world == 1 and not args.no_fusion_block) else None
     # second leg with the SAME --steps / --warmup: the strictly-fp32 step (v_mfma_f32_32x32x2_f32 everywhere), its own roofline
     exact_leg = run_leg("f32") if (args.precision != "f32" and not args.no_exact_f32) else None
     # third leg, same --steps / --warmup: BASELINE.json configs[2] (16-bit MFMA arithmetic): fp16 operands, one MFMA per product
@@ -533,7 +538,7 @@ def main():
     # fourth leg: BASELINE.json configs[2] AS STATED -- bf16 storage of activations / saved tensors / activation gradients (ops16)
     s16_leg = run_leg("bf16") if (args.precision == "f16x3" and not args.no_bf16) else None
     s16_peak_mem = round(torch.cuda.max_memory_allocated() / 2**30, 2) if s16_leg is not None else None
-    fusion_s16 = fusion_block_leg("bf16") if (s16_leg is not None and world == 1) else None
+    fusion_s16 = fusion_block_leg("bf16") if (s16_leg is not None and world == 1 and not args.no_fusion_block) else None
     ops.set_precision(args.precision)
 
     # secondary figure (outside the metric, which excludes the optimizer): the fused Adam step over

@@ -714,6 +714,68 @@ extern "C" int glf_split_f16_packed(const float* x, int64_t rows, int cols, int6
     return glf::launch_split_packed(x, rows, cols, ld, amax, out, ldo, glf::S(stream));
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// Skinny NT: M <= 64 rows (the ASPP pooled branch, deeplabv3.py:123-135: ONE row per frame).  The tile kernels put such a
+// shape on one or two workgroups that walk the whole K alone -- 64 dependent global-memory round trips, 0.2 ms for 34 MFLOP
+// at 64 x 256 x 2048.  Here a workgroup owns SK_COLS output columns for all rows: thread = (row, one of four k-lanes), the
+// B rows are the same address across the rows of a wave (broadcast out of L1), four independent A loads in flight per thread,
+// the k-lanes folded with two shuffles.  fp32 FMA arithmetic (exact-fp32 grade under every precision setting).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int SK_COLS = 2;
+__global__ __launch_bounds__(256) void gemm_skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, float alpha,
+                                                            int accumulate, float* __restrict__ amax_c) {
+    const int tid = threadIdx.x, kl = tid & 3, m = tid >> 2;
+    const int n0 = blockIdx.x * SK_COLS;
+    const float* a = A + (long long)min(m, M - 1) * lda + 4 * kl;
+    const float* b[SK_COLS];
+#pragma unroll
+    for (int j = 0; j < SK_COLS; ++j) b[j] = B + (long long)min(n0 + j, N - 1) * ldb + 4 * kl;
+    float acc[SK_COLS] = {};
+    int k = 0;
+    for (; k + 64 <= K; k += 64) {
+        float4 av[4], bv[SK_COLS][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = *reinterpret_cast<const float4*>(a + k + 16 * u);
+#pragma unroll
+        for (int j = 0; j < SK_COLS; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[j][u] = *reinterpret_cast<const float4*>(b[j] + k + 16 * u);
+#pragma unroll
+        for (int j = 0; j < SK_COLS; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc[j] += av[u].x * bv[j][u].x + av[u].y * bv[j][u].y + av[u].z * bv[j][u].z + av[u].w * bv[j][u].w;
+    }
+    for (; k < K; k += 16) {
+        const float4 av = *reinterpret_cast<const float4*>(a + k);
+#pragma unroll
+        for (int j = 0; j < SK_COLS; ++j) {
+            const float4 bv = *reinterpret_cast<const float4*>(b[j] + k);
+            acc[j] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+        }
+    }
+    float cmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < SK_COLS; ++j) {
+        float v = acc[j];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (kl == 0 && m < M && n0 + j < N) {
+            v = v * alpha + (bias ? bias[n0 + j] : 0.f);
+            float* c = C + (long long)m * ldc + n0 + j;
+            if (accumulate) v += *c;
+            *c = v;
+            cmax = fmaxf(cmax, fabsf(v));
+        }
+    }
+    if (amax_c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+        if ((tid & 63) == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_c), __float_as_uint(cmax));
+    }
+}
+
 extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, float* C,
                            const glf_gemm_params* p, glf_stream_t stream) {
     if (int rc = glf::ensure_init()) return rc;
@@ -726,6 +788,12 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     a.vec_a = aligned16(A) && (p->lda % 4 == 0) && (p->batch_stride_a % 4 == 0);
     a.vec_b = aligned16(B) && (p->ldb % 4 == 0) && (p->batch_stride_b % 4 == 0) && (p->tap_stride_b % 4 == 0);
     dim3 grid(a.tiles_m * a.tiles_n, 1, p->batch);
+    if (p->M <= 64 && !p->gather && p->taps == 1 && p->batch == 1 && !p->rect && !p->colstats && !p->a_presplit && !p->b_presplit && a.vec_a &&
+        a.vec_b && p->K % 16 == 0 && p->N >= 64) {
+        hipLaunchKernelGGL(gemm_skinny_nt_kernel, dim3((p->N + SK_COLS - 1) / SK_COLS), dim3(256), 0, glf::S(stream), A, B, bias, C, p->M, p->N, p->K,
+                           p->lda, p->ldb, p->ldc, p->alpha, p->accumulate, p->amax_c);
+        return glf::check_launch("gemm_nt(skinny)");
+    }
     if (p->rect == 2) {                 // region mode: f16x3 kernels only (see region_of in gemm_common.h)
         GLF_REQUIRE(prec >= 2 && glf::f16s_rows_ok(a), GLF_ERR_UNSUPPORTED,
                     "glf_gemm_nt: rect = 2 (region mode) exists on the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands)");

@@ -920,8 +920,10 @@ class Conv2dFn(Function):
             if colstats is not None:
                 raise RuntimeError("conv2d: fused column statistics are not available for a conv evaluated as per-tap rectangles")
         am_w, am_x = amax_of(weight), amax_of(x)
-        ok = nt_presplit_ok(cin, cin, cin)
         x_pk = packed_only(x)                # the producing BatchNorm wrote the activation as a packed image (no fp32 form exists)
+        # <= 64 output rows (the ASPP pooled branch: one row per frame): glf_gemm_nt's skinny kernel takes plain fp32 operands
+        skinny = plain and n * ho * wo <= 64 and cout >= 64 and cin % 16 == 0 and not x_pk and colstats is None
+        ok = nt_presplit_ok(cin, cin, cin) and not skinny
         if x_pk and not (ok and am_x is not None and takes_packed_input(weight)):
             raise RuntimeError("glfusion_amd: a packed-only activation reached a convolution that cannot consume it")
         ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or packed_hit(x, am_x) is not None)

@@ -540,12 +540,6 @@ int glf_dropout(const float* x, float* y, int64_t numel, float p, uint64_t seed,
 int glf_amax_combine(const float* a, const float* b, float scale, int sum, float* out, glf_stream_t s);
 /* *counter += inc (a device uint64), stream-ordered. */
 int glf_counter_add(uint64_t* counter, uint64_t inc, glf_stream_t s);
-/* Measurement aid (bench.py's roofline.power_limited_peak_measured; not on the path): `blocks` workgroups of 8 wavefronts
- * each issue 4 * iters back-to-back v_mfma_f32_32x32x16_f16 on register operands derived from `seed` (0 = all ones, else
- * pseudo-random halves in [-0.5, 0.5)) with no memory traffic, then store one float per thread to out[blocks * 512].
- * FLOPs of a launch = blocks * 8 * iters * 4 * 32768.  With random operands the matrix cores of an MI355X are power-limited
- * well below the 2.5 PFLOP/s a constant-operand run reaches; timing this launch on the box a bench runs on says how far. */
-int glf_probe_mfma_f16(float* out, int blocks, int iters, uint32_t seed, glf_stream_t s);
 /* Local gate (a5, ours.py:1802-1816): a[r] = sigmoid(w * max_c sigmoid(cls[r][c]) * sigmoid(ctr[r])),
  * y[r][:] = f[r][:] * a[r].  argmax (int32 per row) is saved for backward. */
 int glf_gate_fwd(const float* cls, int ncls, const float* ctr, const float* f, float* y, float* a,

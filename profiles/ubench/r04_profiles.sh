@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-4 judged artefacts, collected in one gpurun call and stamped (profiles/stamp.py: git hash + hash of the kernel sources; bench.py
 # refuses a PMC-derived figure whose stamp does not match the sources it runs on).  Usage on the GPU box:
-#   GLF_GIT_HASH=<hash> bash profiles/ubench/r04_profiles.sh [part ...]     parts: ks pmc busy bench (default: all)
+#   GLF_GIT_HASH=<hash> bash profiles/ubench/r04_profiles.sh [part ...]     parts: ks shapes pmc busy bench (default: all)
 # Every rocprofv3 pass has the program itself after `--`; --pmc passes carry --kernel-trace only, one counter group per pass.
 export PYTHONUNBUFFERED=1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 mkdir -p $O
-PARTS=${@:-ks pmc busy bench}
-COMMON="--no-config3 --no-cpu-baseline --no-exact-f32 --no-other-mode --no-bf16"
+PARTS=${@:-ks shapes pmc busy bench}
+COMMON="--no-config3 --no-cpu-baseline --no-exact-f32 --no-other-mode --no-bf16 --no-fusion-block"
 cd /tmp && export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 
@@ -23,6 +23,14 @@ if has ks; then
     python3 $R/profiles/ubench/kstats_groups.py $O/r04_bench_c2_${prec}_one_stream_kernel_stats.csv 11 > $O/r04_bench_c2_${prec}_one_stream_groups.txt
     tail -4 $O/r04_bench_c2_${prec}_one_stream_groups.txt
   done
+fi
+
+if has shapes; then
+  # per-shape contraction tables (event pairs around every contraction launch of one-stream steps, outside the timed region)
+  for prec in f16x3 bf16; do
+    GLF_BENCH_DUMP=$O/r04_bench_c2_per_shape timeout -k 10 300 python3 $R/bench.py --precision $prec --steps 4 --warmup 2 $COMMON > /tmp/ps_$prec.log 2>&1 || { tail -3 /tmp/ps_$prec.log; exit 1; }
+  done
+  ls $O | grep per_shape
 fi
 
 if has pmc; then

@@ -1,5 +1,7 @@
 """GPU: every HIP kernel (through the C ABI, via glfusion_amd.ops) against a plain PyTorch fp32
 CPU reference of the same op on the same seeded inputs.  Tolerances are written per test."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -33,7 +35,9 @@ def ops(precision):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K,batch", [(300, 70, 52, 1), (128, 128, 32, 1), (517, 260, 100, 3), (64, 5, 256, 1), (1000, 256, 5, 1)])
+@pytest.mark.parametrize("M,N,K,batch", [(300, 70, 52, 1), (128, 128, 32, 1), (517, 260, 100, 3), (64, 5, 256, 1), (1000, 256, 5, 1),
+                                         # <= 64 rows, K % 16 == 0, N >= 64: glf_gemm_nt's skinny kernel (the ASPP pooled branch's shape last)
+                                         (1, 64, 16, 1), (37, 131, 80, 1), (64, 256, 2048, 1)])
 def test_gemm_nt_nn_tn_plain(ops, M, N, K, batch):
     A = rnd(batch, M, K, seed=1)
     Bnk = rnd(batch, N, K, seed=2)
@@ -841,8 +845,13 @@ def test_fused_inference_stem_equals_the_three_kernel_chain(shape):
 def test_mfma_probe_counts_what_it_claims():
     """glf_probe_mfma_f16 (bench.py's in-run power-limited peak): with constant operands (seed 0: all ones) every accumulator
     element grows by K = 16 per MFMA, so each thread stores 16 elements x 4 accumulators x 16 x iters -- the launch really
-    issued blocks x 8 x iters x 4 MFMAs.  Bad arguments are refused."""
-    from glfusion_amd._lib import lib
+    issued blocks x 8 x iters x 4 MFMAs.  Bad arguments are refused.  The probe lives in the diagnostic library
+    (include/glfusion_diag.h), not in the product one."""
+    import ctypes
+    from glfusion_amd import _lib
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libglfusion_diag.so"))
+    lib.glf_probe_mfma_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
+    assert not hasattr(ctypes.CDLL(_lib.LIB_PATH), "glf_probe_mfma_f16")
     blocks, iters = 8, 10
     out = torch.zeros(blocks * 512, device=DEV)
     assert lib.glf_probe_mfma_f16(out.data_ptr(), blocks, iters, 0, None) == 0

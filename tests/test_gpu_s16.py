@@ -375,7 +375,7 @@ def test_s16_tpavi_single_call_equals_composed_sequence(training, monkeypatch):
     (z1, dx1, g1, b1), (z0, dx0, g0, b0) = res
     assert torch.equal(z1, z0) and torch.equal(dx1, dx0)
     for k in g0:
-        assert torch.equal(g1[k], g0[k]), k
+        assert (g0[k] is None and g1[k] is None) or torch.equal(g1[k], g0[k]), k
     for k in b0:
         assert torch.equal(b1[k], b0[k]), k
 
