@@ -638,6 +638,76 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// the vector form with SL slice lanes per output (lane l adds slices l, l + SL, ... in double; the lanes meet in LDS in lane order):
+// with one thread per float4 a layer-1 gradient (64 x 256 outputs, hundreds of slices) was a few thousand threads walking hundreds
+// of loads one after the other -- ~100 us for 24 MB
+template <int SL>
+__global__ __launch_bounds__(256) void tn_reduce_lanes_kernel(const float* __restrict__ partial, float* __restrict__ Cb, int M, int N, int ldc,
+                                                              long long tsb, long long bsc, int split, unsigned tap_mask, int accumulate,
+                                                              int K, int rect, Geo g, float* __restrict__ amax_c) {
+    constexpr int OG = 256 / SL;
+    __shared__ double sh[4][256];
+    unsigned mm = tap_mask;
+    for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
+    const int tap = __ffs(mm) - 1;
+    const int ntap = gridDim.y, bz = blockIdx.z;
+    int pKe = K;
+    if (rect) {
+        int y0, y1, x0, x1;
+        tap_rect(1, tap, g.kw, g.pad, g.dil, g.hs, g.ws, g.hd, g.wd, y0, y1, x0, x1);
+        pKe = g.n_img * (y1 - y0) * (x1 - x0);
+    }
+    int chunk = (K + split - 1) / split;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    const int nvalid = chunk > 0 ? min(split, (pKe + chunk - 1) / chunk) : 0;
+    const long long mn = (long long)M * N;
+    const float* __restrict__ src = partial + ((long long)bz * split * ntap + blockIdx.y) * mn;
+    const long long slice_stride = (long long)ntap * mn;
+    float* __restrict__ C = Cb + (long long)bz * bsc + (long long)tap * tsb;
+    const int n4 = N >> 2;
+    const long long total = (long long)M * n4;
+    const int ol = threadIdx.x % OG, sl = threadIdx.x / OG;
+    float cmax = 0.f;
+    for (long long base = (long long)blockIdx.x * OG; base < total; base += (long long)gridDim.x * OG) {
+        const long long i = base + ol;
+        const bool live = i < total;
+        const long long row = live ? i / n4 : 0;
+        const int c4 = (int)((live ? i : 0) - row * n4) * 4;
+        double ax = 0, ay = 0, az = 0, aw = 0;
+        if (live) {
+            const float* sp = src + row * N + c4;
+            int s_ = sl;
+            for (; s_ + SL < nvalid; s_ += 2 * SL) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + (long long)s_ * slice_stride);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + (long long)(s_ + SL) * slice_stride);
+                ax += (double)v0.x + (double)v1.x; ay += (double)v0.y + (double)v1.y;
+                az += (double)v0.z + (double)v1.z; aw += (double)v0.w + (double)v1.w;
+            }
+            for (; s_ < nvalid; s_ += SL) {
+                const float4 v = *reinterpret_cast<const float4*>(sp + (long long)s_ * slice_stride);
+                ax += v.x; ay += v.y; az += v.z; aw += v.w;
+            }
+        }
+        sh[0][threadIdx.x] = ax; sh[1][threadIdx.x] = ay; sh[2][threadIdx.x] = az; sh[3][threadIdx.x] = aw;
+        __syncthreads();
+        if (sl == 0 && live) {
+#pragma unroll
+            for (int l = 1; l < SL; ++l) { ax += sh[0][l * OG + ol]; ay += sh[1][l * OG + ol]; az += sh[2][l * OG + ol]; aw += sh[3][l * OG + ol]; }
+            float* dst = C + row * ldc + c4;
+            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); ax += o.x; ay += o.y; az += o.z; aw += o.w; }
+            const float4 acc = make_float4((float)ax, (float)ay, (float)az, (float)aw);
+            *reinterpret_cast<float4*>(dst) = acc;
+            cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        }
+        __syncthreads();
+    }
+    if (amax_c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && cmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_c), __float_as_uint(cmax));
+    }
+}
+
 constexpr size_t SMEM_ROWS_NT = (2 * BK * LD_T + 2 * BK * LD_T) * sizeof(float) + 16;
 constexpr size_t SMEM_ROWS_NN = (2 * BK * LD_T + 2 * BK * LD_V) * sizeof(float) + 16;
 constexpr size_t SMEM_TN = (4 * BK * LD_V) * sizeof(float) + 2 * 32 * sizeof(int);
@@ -893,6 +963,19 @@ extern "C" int glf_gemm_tn(const float* A, const float* B, float* C,
     const long long work = vec ? (long long)p->M * (p->N / 4) : (long long)p->M * p->N;
     long long bx = (work + 255) / 256;
     if (bx > 2048) bx = 2048;
+    int lanes = 1;
+    while (vec && lanes < 16 && lanes * 4 <= a.split && work * lanes < 65536) lanes *= 4;
+    if (lanes > 1) {
+        long long bl = (work * lanes + 255) / 256;
+        if (bl > 4096) bl = 4096;
+        if (lanes == 16)
+            hipLaunchKernelGGL((tn_reduce_lanes_kernel<16>), dim3((unsigned)bl, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, p->M, p->N,
+                               p->ldc, (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->accumulate, p->K, a.rect, a.g, p->amax_c);
+        else
+            hipLaunchKernelGGL((tn_reduce_lanes_kernel<4>), dim3((unsigned)bl, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, p->M, p->N,
+                               p->ldc, (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->accumulate, p->K, a.rect, a.g, p->amax_c);
+        return glf::check_launch("gemm_tn(reduce)");
+    }
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)bx, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, p->M, p->N, p->ldc,
                        (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->accumulate, p->K, a.rect, a.g, vec,
                        p->amax_c);

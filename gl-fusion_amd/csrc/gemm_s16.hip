@@ -470,6 +470,30 @@ __global__ __launch_bounds__(NTH, TK_ == 64 ? 2 : 4) void s16_rows_kernel(const 
 // ----------------------------------------------------------------------------------------------------------------------
 // tn kernel
 // ----------------------------------------------------------------------------------------------------------------------
+// output pixels y (of hd) whose source pixel y * stride + o lies inside [0, hs): the band [lo, hi)
+__host__ __device__ inline void tap_band(int o, int stride, int hs, int hd, int& lo, int& hi) {
+    lo = o < 0 ? (-o + stride - 1) / stride : 0;
+    const int top = hs - 1 - o;
+    hi = top < 0 ? 0 : (top / stride + 1 < hd ? top / stride + 1 : hd);
+    if (lo > hi) lo = hi;
+}
+// reduction rows of tap `tap` of a gathered TN contraction in rectangle mode (rect = 1): only the output pixels whose source pixel
+// is inside the map, enumerated image by image, row by row: n_img * (yhi - ylo) * (xhi - xlo)
+__host__ __device__ inline int tn_rect_rows(const Geo& g, int tap, int K) {
+    const int ky = tap / g.kw, kx = tap - ky * g.kw;
+    int ylo, yhi, xlo, xhi;
+    tap_band(ky * g.dil - g.pad, g.stride, g.hs, g.hd, ylo, yhi);
+    tap_band(kx * g.dil - g.pad, g.stride, g.ws, g.wd, xlo, xhi);
+    return (K / (g.hd * g.wd)) * (yhi - ylo) * (xhi - xlo);
+}
+// r / d for 0 <= r < 2^24, d >= 1, inv = 1.f / d: one multiply, one conversion and two corrections instead of an integer division
+__device__ __forceinline__ int fdiv(int r, int d, float inv) {
+    int q = (int)((float)r * inv);
+    if (q * d > r) --q;
+    if ((q + 1) * d <= r) ++q;
+    return q;
+}
+
 constexpr int TN_BN = 128;
 constexpr int TNA_STAGE = TK * TM * 2;           // [64 r][256 m]: 32 KiB
 constexpr int TNB_STAGE = TK * TN_BN * 2;        // [64 r][128 n]: 16 KiB
@@ -507,10 +531,25 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
     const u16* __restrict__ A = args.A + (long long)bz * args.bsa;
     const u16* __restrict__ B = args.B + (long long)bz * args.bsb;
 
+    // rectangle mode (gathered taps that fall mostly into the padding: the ASPP rates): the reduction of a tap runs over ITS in-range
+    // output pixels only, enumerated compactly; a slice is the same number of rows for every tap, so a tap with a small rectangle uses
+    // fewer slices (the others return here) and all workgroups reduce equally long
+    const bool RECT = GATHER && args.rect != 0;
+    int q_ylo = 0, q_xlo = 0, q_h = g_hd, q_w = g_wd;
+    if (RECT) {
+        const int ky = tap / g_kw, kx = tap - ky * g_kw;
+        int yhi_, xhi_;
+        tap_band(ky * g_dil - g_pad, g_stride, g_hs, g_hd, q_ylo, yhi_);
+        tap_band(kx * g_dil - g_pad, g_stride, g_ws, g_wd, q_xlo, xhi_);
+        q_h = yhi_ - q_ylo; q_w = xhi_ - q_xlo;
+    }
+    const int q_hw = q_h * q_w;
+    const int k_rows = RECT ? (pK / (g_hd * g_wd)) * q_hw : pK;
+    const float q_inv_hw = 1.0f / (float)(q_hw > 0 ? q_hw : 1), q_inv_w = 1.0f / (float)(q_w > 0 ? q_w : 1);
     int chunk = (pK + p_split - 1) / p_split;
     chunk = ((chunk + TK - 1) / TK) * TK;
     const int r0 = sl * chunk;
-    const int r1 = min(pK, r0 + chunk);
+    const int r1 = min(k_rows, r0 + chunk);
     if (r0 >= r1) return;
 
     // staging: A instruction j of this wave holds reduction rows wave * 8 + 2 j + (lane >> 5), 16-byte piece lane & 31 of the
@@ -547,6 +586,32 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
         unsigned char* sa = smem + stage * TN_STAGE + (wave * AJ) * 1024;
         unsigned char* sb = smem + stage * TN_STAGE + TNA_STAGE + (wave * BJ) * 1024;
         const u16* At = A + (long long)rbase * p_lda;
+        if (RECT) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int r = rbase + wave * 8 + 2 * j + a_rl;
+                const u16* src = p_zero;
+                if (r < r1 && a_col[j] >= 0) {
+                    const int n = fdiv(r, q_hw, q_inv_hw), rem = r - n * q_hw;
+                    const int yy = fdiv(rem, q_w, q_inv_w), xx = rem - yy * q_w;
+                    src = A + ((long long)(n * g_hd + q_ylo + yy) * g_wd + q_xlo + xx) * p_lda + a_col[j];
+                }
+                glds16(src, sa + j * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int r = rbase + wave * 8 + 4 * j + b_rl;
+                const u16* src = p_zero;
+                if (r < r1 && b_col[j] >= 0) {
+                    const int n = fdiv(r, q_hw, q_inv_hw), rem = r - n * q_hw;
+                    const int yy = fdiv(rem, q_w, q_inv_w), xx = rem - yy * q_w;
+                    const int sy = (q_ylo + yy) * g_stride + oy, sx = (q_xlo + xx) * g_stride + ox;       // in range by construction
+                    src = B + ((long long)(n * g_hs + sy) * g_ws + sx) * p_ldb + b_col[j];
+                }
+                glds16(src, sb + j * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int r = rbase + wave * 8 + 2 * j + a_rl;
@@ -644,7 +709,7 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
         yhi = (g_hs - 1 - oy) < 0 ? 0 : (ymax + 1 < g_hd ? ymax + 1 : g_hd);
         if (ylo > yhi) ylo = yhi;
     }
-    const bool banded = GATHER && (ylo > 0 || yhi < g_hd);
+    const bool banded = GATHER && !RECT && (ylo > 0 || yhi < g_hd);
     auto next_valid = [&](int r) __attribute__((always_inline)) -> int {
         if (!banded || r >= r1) return r;
         if (ylo >= yhi) return r1;
@@ -718,32 +783,64 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
         }
 }
 
-// second stage of the split-K reduction: C_tap = sum over the slices of their partial slabs, in slice order
+// second stage of the split-K reduction: C_tap = sum over the slices of their partial slabs, in a fixed order.  SL slice lanes share
+// an output (lane l adds slices l, l + SL, ...; the lanes meet in LDS, lane order): with one thread per output a 378-slice layer-1
+// gradient was 378 dependent-latency loads on 4 096 threads -- 100 us for 24 MB.
+template <int SL>
 __global__ __launch_bounds__(256) void s16_tn_reduce_kernel(const float* __restrict__ partial, void* __restrict__ Cv, int c_bf16, int M, int N, int ldc,
-                                                            long long tsb, long long bsc, int split, unsigned tap_mask, int K) {
+                                                            long long tsb, long long bsc, int split, unsigned tap_mask, int K, int rect, Geo g) {
+    constexpr int OG = 256 / SL;                                      // outputs (float4) per block
+    __shared__ float4 sh[SL > 1 ? 256 : 1];
     unsigned mm = tap_mask;
     for (int i = 0; i < (int)blockIdx.y; ++i) mm &= mm - 1;
     const int tap = __ffs(mm) - 1;
     const int ntap = gridDim.y, bz = blockIdx.z;
     int chunk = (K + split - 1) / split;
     chunk = ((chunk + TK - 1) / TK) * TK;
-    const int nvalid = min(split, (K + chunk - 1) / chunk);           // slices that ran (the others returned early)
+    const int k_rows = rect ? tn_rect_rows(g, tap, K) : K;
+    const int nvalid = min(split, (k_rows + chunk - 1) / chunk);      // slices that ran (the others returned early); 0: an empty rectangle
     const long long mn = (long long)M * N;
     const float* __restrict__ src = partial + ((long long)bz * split * ntap + blockIdx.y) * mn;
     const long long slice_stride = (long long)ntap * mn;
     const int n4 = N >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)M * n4; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / n4;
-        const int c4 = (int)(i - row * n4) * 4;
+    const long long total = (long long)M * n4;
+    const int ol = threadIdx.x % OG, sl = threadIdx.x / OG;
+    for (long long base = (long long)blockIdx.x * OG; base < total; base += (long long)gridDim.x * OG) {
+        const long long i = base + ol;
+        const bool live = i < total;
+        const long long row = live ? i / n4 : 0;
+        const int c4 = (int)((live ? i : 0) - row * n4) * 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* sp = src + row * N + c4;
-        for (int s = 0; s < nvalid; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(sp + s * slice_stride);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (live) {
+            const float* sp = src + row * N + c4;
+            int sidx = sl;
+            for (; sidx + 3 * SL < nvalid; sidx += 4 * SL) {
+                const float4 v0 = *reinterpret_cast<const float4*>(sp + (long long)sidx * slice_stride);
+                const float4 v1 = *reinterpret_cast<const float4*>(sp + (long long)(sidx + SL) * slice_stride);
+                const float4 v2 = *reinterpret_cast<const float4*>(sp + (long long)(sidx + 2 * SL) * slice_stride);
+                const float4 v3 = *reinterpret_cast<const float4*>(sp + (long long)(sidx + 3 * SL) * slice_stride);
+                a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+                a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+            }
+            for (; sidx < nvalid; sidx += SL) {
+                const float4 v = *reinterpret_cast<const float4*>(sp + (long long)sidx * slice_stride);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
         }
-        const long long o = (long long)bz * bsc + (long long)tap * tsb + row * ldc + c4;
-        if (c_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(Cv) + o) = make_uint2(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w));
-        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o) = a;
+        if (SL > 1) {
+            sh[threadIdx.x] = a;
+            __syncthreads();
+            if (sl == 0) {
+#pragma unroll
+                for (int l = 1; l < SL; ++l) { const float4 v = sh[l * OG + ol]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            }
+            __syncthreads();
+        }
+        if (sl == 0 && live) {
+            const long long o = (long long)bz * bsc + (long long)tap * tsb + row * ldc + c4;
+            if (c_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(Cv) + o) = make_uint2(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w));
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + o) = a;
+        }
     }
 }
 
@@ -813,6 +910,8 @@ extern "C" int glf_s16_gemm_nt(const void* A, const void* B, const float* bias, 
     GLF_REQUIRE(p->rect == 0 || p->rect == 2, GLF_ERR_UNSUPPORTED, "s16_gemm_nt: rect must be 0 or 2 (region mode); per-tap rectangles need float atomics");
     GLF_REQUIRE(!p->colstats || p->batch == 1, GLF_ERR_UNSUPPORTED, "s16_gemm_nt: colstats needs batch 1");
     S16Args a = make_args16(A, B, bias, C, p);
+    // (halving the column tile of the region-mode ASPP forward launches, whose 392 workgroups leave slots empty while the longest tap
+    // chains run, was measured: +1.4 ms per step -- profiles/r04_ab_s16.txt)
     const int bn = p->N <= 64 ? 64 : 128;
     a.tiles_n = (p->N + bn - 1) / bn;
     long long tiles_m = (p->M + TM - 1) / TM;
@@ -859,12 +958,15 @@ extern "C" int glf_s16_gemm_tn(const void* A, const void* B, void* C, const glf_
     if (int rc = glf::ensure_init()) return rc;
     if (int rc = validate16(p, A, B, C, "s16_gemm_tn")) return rc;
     GLF_REQUIRE(p->gather != 2, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: transposed gather is not defined for the reduction form");
-    GLF_REQUIRE(!p->colstats && !p->rect && !p->accumulate, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: colstats / rect / accumulate are not built");
+    GLF_REQUIRE(!p->colstats && !p->accumulate, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: colstats / accumulate are not built");
+    GLF_REQUIRE(p->rect == 0 || (p->rect == 1 && p->gather == 1 && p->split > 1), GLF_ERR_UNSUPPORTED,
+                "s16_gemm_tn: rect = 1 (per-tap rectangles) needs a forward gather and split > 1 (the slabs of taps with empty rectangles are summed as zero)");
     GLF_REQUIRE(p->M % 8 == 0 && p->N % 8 == 0, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: M and N must be multiples of 8 (got %d, %d)", p->M, p->N);
     if (p->gather) GLF_REQUIRE((long long)p->n_img * p->hd * p->wd == p->K, GLF_ERR_BAD_SHAPE, "s16_gemm_tn: K (%d rows) != n_img*hd*wd", p->K);
     S16Args a = make_args16(A, B, nullptr, C, p);
     const int ntap = __builtin_popcount(p->tap_mask);
     if (ntap == 0) return GLF_OK;
+    a.rect = p->rect;
     GLF_REQUIRE((long long)p->batch * a.split <= 65535, GLF_ERR_BAD_SHAPE, "s16_gemm_tn: batch*split too large");
     a.tiles_n = (p->N + TN_BN - 1) / TN_BN;
     const int tiles_m = (p->M + TM - 1) / TM;
@@ -882,9 +984,17 @@ extern "C" int glf_s16_gemm_tn(const void* A, const void* B, void* C, const glf_
     if (int rc = glf::check_launch("s16_gemm_tn")) return rc;
     if (!two_stage) return GLF_OK;
     const long long work = (long long)p->M * (p->N / 4);
-    long long bx = (work + 255) / 256;
-    if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(s16_tn_reduce_kernel, dim3((unsigned)bx, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, a.c_bf16, p->M, p->N,
-                       p->ldc, (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->K);
+    // slice lanes per output: enough threads to keep the slabs' loads in flight (work x lanes >= ~64 k threads), at most 16
+    int lanes = 1;
+    while (lanes < 16 && lanes * 4 <= a.split && work * lanes < 65536) lanes *= 4;
+#define GLF_S16_REDUCE(SL_)                                                                                                          \
+    {                                                                                                                                \
+        long long bx = (work + (256 / SL_) - 1) / (256 / SL_);                                                                       \
+        if (bx > 4096) bx = 4096;                                                                                                    \
+        hipLaunchKernelGGL((s16_tn_reduce_kernel<SL_>), dim3((unsigned)bx, ntap, p->batch), dim3(256), 0, glf::S(stream), a.partial, C, a.c_bf16, \
+                           p->M, p->N, p->ldc, (long long)p->tap_stride_b, (long long)p->batch_stride_c, a.split, p->tap_mask, p->K, a.rect, a.g); \
+    }
+    if (lanes == 16) GLF_S16_REDUCE(16) else if (lanes == 4) GLF_S16_REDUCE(4) else GLF_S16_REDUCE(1)
+#undef GLF_S16_REDUCE
     return glf::check_launch("s16_gemm_tn(reduce)");
 }

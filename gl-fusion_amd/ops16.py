@@ -26,6 +26,8 @@ _p, _stream, _contig = _o._p, _o._stream, _o._contig
 DT_F32, DT_BF16 = 0, 1
 # block sequences through their single-call C entry points (glf_s16_tpavi_fwd / _bwd); 0 = composed from Python, the same launches
 BLOCK_CALLS = os.environ.get("GLF_BLOCK_CALLS", "1") != "0"
+# gathered weight gradients whose taps fall mostly into the padding reduce over per-tap rectangles (glf_s16_gemm_tn rect = 1); 0 = banded K-tile skipping only
+RECT_WGRAD = os.environ.get("GLF_S16_RECT_WGRAD", "1") != "0"
 
 
 def _chk16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
@@ -231,13 +233,23 @@ class Conv2d16Fn(Function):
             mask = 1 if plain else _o.tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
             ntap = bin(mask).count("1")
             split = tn_split16(rows_o, cout, cin, ntap)
+            # taps that fall mostly into the padding (ASPP rates 12 / 24): rectangle mode -- a tap reduces over its in-range output
+            # pixels only.  A slice is the same number of rows for every tap (a short rectangle uses fewer slices), so the slice
+            # count is the one of the in-range rows scaled back up to the whole map.
+            rect = 0
+            if RECT_WGRAD and not plain and stride == 1 and ntap > 1 and rows_o >= 2048:
+                frac = _o.rect_fraction(1, ho, wo, h, w, kh, kw, pad, dil, mask)
+                if frac < 0.8:
+                    s_in = tn_split16(max(512, int(rows_o * frac)), cout, cin, ntap)
+                    split = max(2, min(int(s_in / max(frac, 0.02) + 0.999), max(2, rows_o // 512), 65535))
+                    rect = 1
             full = mask == (1 << taps) - 1
             if taps == 1 and full:
                 dwt = _o.grad_out(weight, (1, cout, cin), x.device)
             else:
                 dwt = (torch.empty if full else _o.zeros)(taps, cout, cin, dtype=torch.float32, device=x.device)
             gemm16("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask, tap_stride_b=cout * cin,
-                   gather=0 if plain else 1, geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split)
+                   gather=0 if plain else 1, geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect)
             if taps == 1:
                 dw = dwt.view(wshape)
             else:
