@@ -1,11 +1,12 @@
-timeout -k 10 700 python -m pytest tests/test_gpu_s16.py tests/test_gpu_ops.py -x -q > gpurun_out/t5.log 2>&1; echo rc=$?; tail -3 gpurun_out/t5.log
+# A/B of 16-bit-storage switches on one box: bench.py --precision bf16 (ms per step)
 b() { timeout -k 10 200 python bench.py --precision $1 --steps 6 --warmup 2 --no-exact-f32 --no-config3 --no-bf16 --no-cpu-baseline --no-other-mode --no-fusion-block 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('$2', d['ms_per_step'])"; }
 b bf16 "bf16 default"
-GLF_S16_RECT_WGRAD=0 b bf16 "bf16 rect_wgrad=0"
-GLF_S16_RBN=64 b bf16 "bf16 rbn=64"
+GLF_S16_RED_TPR=32 b bf16 "bf16 red_tpr=32"
+GLF_S16_RED_TPR=64 b bf16 "bf16 red_tpr=64"
+GLF_S16_RED_TPR=128 b bf16 "bf16 red_tpr=128"
 b bf16 "bf16 default"
-b f16x3 "f16x3"
+GLF_S16_RED_TPR=32 b bf16 "bf16 red_tpr=32"
