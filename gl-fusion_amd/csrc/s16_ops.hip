@@ -61,12 +61,12 @@ __device__ __forceinline__ float bn_val(float x, float mu, float is, float ga, f
 // ----------------------------------------------------------------------------------------------------------------------
 constexpr int RT = 256;
 
-__host__ __device__ inline int red_slices(int rows, int c, int tpr_max = RT) {
+__host__ __device__ inline int red_slices(int rows, int c) {
     // A workgroup streams `per` rows of all its channels; the grid must put enough loads in flight to reach the HBM rate (these
     // reductions are latency-bound at low occupancy: 512 workgroups of 12 dependent iterations each ran at 1 TB/s), so: ~64 rows
     // per row lane, at most 1 024 workgroups (one f64 atomic per column and slice).
     const int c8 = c > 8 ? c / 8 : 1;
-    const int tpr = c8 < tpr_max ? c8 : tpr_max;
+    const int tpr = c8 < 256 ? c8 : 256;
     const int rpp = 256 / tpr;                        // rows per pass of a workgroup
     int s = (rows + 16 * rpp - 1) / (16 * rpp);       // 16 rows per thread
     const int cblocks = (c8 + tpr - 1) / tpr;
@@ -79,11 +79,11 @@ __host__ __device__ inline int red_slices(int rows, int c, int tpr_max = RT) {
 // sums over its <= ~16-64 rows, four rows' loads in flight at a time; the row lanes of a workgroup are folded in double through LDS
 // and ONE f64 atomic per column, statistic and workgroup reaches memory.
 template <class Op>
-__global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ sums, int tpr_max) {
+__global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ sums) {
     __shared__ float sh[RT * 16];
     const int tid = threadIdx.x;
     const int c8 = c >> 3;
-    const int tpr = c8 < tpr_max ? c8 : tpr_max;  // threads per row (a power of two <= RT, or c8)
+    const int tpr = c8 < RT ? c8 : RT;            // threads per row
     const int rpp = RT / tpr;                     // rows per pass
     const int ct = tid % tpr, rl = tid / tpr;
     const int slice = blockIdx.x;
@@ -182,12 +182,9 @@ struct OpColsum16 {         // (dy, 0)
 
 template <class Op>
 int launch_colreduce16(Op op, int rows, int c, double* sums, hipStream_t s) {
-    // threads per row: a workgroup of 256 covers tpr * 8 columns with 256 / tpr row lanes that are folded in LDS before the atomics --
-    // narrower column blocks mean fewer f64 atomics per byte read (GLF_S16_RED_TPR: experiment switch)
-    static const int tpr_max = []() { const char* e = getenv("GLF_S16_RED_TPR"); const int v = e ? atoi(e) : RT; return (v >= 8 && v <= RT && (v & (v - 1)) == 0) ? v : RT; }();
-    const int slices = red_slices(rows, c, tpr_max);
-    const int c8 = c / 8, tpr = c8 < tpr_max ? c8 : tpr_max;
-    hipLaunchKernelGGL((s16_colreduce_kernel<Op>), dim3(slices, (c8 + tpr - 1) / tpr), dim3(RT), 0, s, op, rows, c, slices, sums, tpr_max);
+    const int slices = red_slices(rows, c);
+    const int c8 = c / 8, tpr = c8 < RT ? c8 : RT;
+    hipLaunchKernelGGL((s16_colreduce_kernel<Op>), dim3(slices, (c8 + tpr - 1) / tpr), dim3(RT), 0, s, op, rows, c, slices, sums);
     return glf::check_launch("s16_colreduce");
 }
 
