@@ -875,6 +875,12 @@ extern "C" int glf_gemm_nt(const float* A, const float* B, const float* bias, fl
     }
     GLF_REQUIRE(!p->colstats || (prec >= 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
                 "glf_gemm_nt: colstats is honoured by the f16x3 kernels only (precision 2, K %% 32 == 0, aligned operands, no rect = 1, batch 1)");
+    // colmax is produced by the wide-store (LDS-parked) epilogue of the split-fp16 kernels only: refuse it wherever a call would run
+    // another epilogue (a zero colmax would make glf_bn_apply_from_sums bound max|y| too low and the packed image overflow its scale)
+    GLF_REQUIRE(!p->colmax || (p->colstats && prec >= 2 && glf::f16s_rows_ok(a) && p->rect != 1 && p->ldc % 4 == 0 && p->N % 4 == 0 && aligned16(C) &&
+                               p->batch_stride_c % 4 == 0),
+                GLF_ERR_UNSUPPORTED, "glf_gemm_nt: colmax needs colstats, precision 3 / 4 on the aligned fast path, no rect = 1, and a 16-byte aligned C with "
+                "ldc, N and batch_stride_c multiples of 4 (the wide-store epilogue is the one that folds it)");
     if (prec == 1 && glf::bf16s_rows_ok(a)) return glf::launch_rows_bf16s(a, grid, p->gather != 0, glf::S(stream));
     if (p->a_presplit || p->b_presplit)
         GLF_REQUIRE(prec >= 2 && glf::f16s_rows_ok(a) && (!p->a_presplit || p->amax_a) && (!p->b_presplit || p->amax_b), GLF_ERR_UNSUPPORTED,

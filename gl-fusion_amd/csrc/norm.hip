@@ -207,9 +207,13 @@ __global__ __launch_bounds__(RT) void bnbwd_reduce_kernel(OpBnBwd op, int rows, 
 // workgroup into a zero-filled [2][c] buffer (consecutive threads own consecutive columns: a wave's atomics cover 512 contiguous
 // bytes), and one atomicMax per column for the two maxima the packed-gradient bound needs.  bn_bwd_apply_kernel finishes the sums
 // in its prologue: two launches per BatchNorm backward instead of three (the finalize kernels were 221 launches of ~14 us per step).
+// Column blocks are FUSED_TPR float4 wide (64 columns): what limits these reductions is the number of f64 atomics that land on one
+// address -- same-address atomics are serialised by the L2, ~25-30 ns each -- so many narrow column blocks with few row slices each
+// beat whole rows (profiles/r04_bn_reduce_sweep.txt, measured on the 16-bit twin of this kernel).
+constexpr int FUSED_TPR = 16;
 __host__ __device__ inline int fused_slices(int rows, int c) {
     const int c4 = c > 4 ? c / 4 : 1;
-    const int tpr = c4 < RT ? c4 : RT;
+    const int tpr = c4 < FUSED_TPR ? c4 : FUSED_TPR;
     const int rpp = RT / tpr;
     int s = (rows + 16 * rpp - 1) / (16 * rpp);
     const int cblocks = (c4 + tpr - 1) / tpr;
@@ -217,12 +221,16 @@ __host__ __device__ inline int fused_slices(int rows, int c) {
     if (cap < 1) cap = 1;
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
+// HAS2: second gradient addend; RM: 0 = no ReLU, 1 = sign bytes, 2 = sign recomputed from x, 3 = sign of the saved output y.
+// The loads of FOUR rows are issued back to back before any arithmetic (through the generic op() the compiler emitted one
+// dependent load -> wait chain per row, the coefficient vectors re-loaded for every row).
+template <bool HAS2, int RM>
 __global__ __launch_bounds__(RT) void bnbwd_reduce_atomic_kernel(OpBnBwd op, int rows, int c, int slices, double* __restrict__ sums,
                                                                  float* __restrict__ cmax) {
     __shared__ float sh[RT * 8];                  // [statistic][row lane][column] for the sums, reused for the maxima
     const int tid = threadIdx.x;
     const int c4 = c >> 2;
-    const int tpr = c4 < RT ? c4 : RT;
+    const int tpr = c4 < FUSED_TPR ? c4 : FUSED_TPR;
     const int rpp = RT / tpr;
     const int ct = tid % tpr, rl = tid / tpr;
     const int slice = blockIdx.x;
@@ -232,23 +240,54 @@ __global__ __launch_bounds__(RT) void bnbwd_reduce_atomic_kernel(OpBnBwd op, int
         const int cc = cb + ct;
         float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, mg = sa, mx = sa;
         if (cc < c4 && rl < rpp) {
-            const float4 mu = *reinterpret_cast<const float4*>(op.mean + cc * 4);
-            const float4 is = *reinterpret_cast<const float4*>(op.invstd + cc * 4);
-            auto acc1 = [&](int r) __attribute__((always_inline)) {
-                float4 a, b;
-                op(r, cc * 4, a, b);
+            const int c0 = cc * 4;
+            const float4 mu = *reinterpret_cast<const float4*>(op.mean + c0);
+            const float4 is = *reinterpret_cast<const float4*>(op.invstd + c0);
+            float4 ga = mu, be = mu;
+            if (RM == 2) { ga = *reinterpret_cast<const float4*>(op.gamma + c0); be = *reinterpret_cast<const float4*>(op.beta + c0); }
+            auto fold = [&](float4 a, const float4 a2, const float4 xx, const float4 yy, unsigned m) __attribute__((always_inline)) {
+                if (HAS2) { a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; }
+                if (RM == 2) {
+                    m = (bn_val(xx.x, mu.x, is.x, ga.x, be.x) > 0.f ? 1u : 0u) | (bn_val(xx.y, mu.y, is.y, ga.y, be.y) > 0.f ? 2u : 0u) |
+                        (bn_val(xx.z, mu.z, is.z, ga.z, be.z) > 0.f ? 4u : 0u) | (bn_val(xx.w, mu.w, is.w, ga.w, be.w) > 0.f ? 8u : 0u);
+                } else if (RM == 3) {
+                    m = (yy.x > 0.f ? 1u : 0u) | (yy.y > 0.f ? 2u : 0u) | (yy.z > 0.f ? 4u : 0u) | (yy.w > 0.f ? 8u : 0u);
+                }
+                if (RM != 0) { a.x = (m & 1u) ? a.x : 0.f; a.y = (m & 2u) ? a.y : 0.f; a.z = (m & 4u) ? a.z : 0.f; a.w = (m & 8u) ? a.w : 0.f; }
+                const float4 xh = make_float4((xx.x - mu.x) * is.x, (xx.y - mu.y) * is.y, (xx.z - mu.z) * is.z, (xx.w - mu.w) * is.w);
                 sa.x += a.x; sa.y += a.y; sa.z += a.z; sa.w += a.w;
-                sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
+                sb.x += a.x * (xx.x - mu.x) * is.x; sb.y += a.y * (xx.y - mu.y) * is.y; sb.z += a.z * (xx.z - mu.z) * is.z; sb.w += a.w * (xx.w - mu.w) * is.w;
                 if (cmax) {
-                    const float4 xx = *reinterpret_cast<const float4*>(op.x + (long long)r * op.ldx + cc * 4);   // (the load op() made: CSE'd)
                     mg.x = fmaxf(mg.x, fabsf(a.x)); mg.y = fmaxf(mg.y, fabsf(a.y)); mg.z = fmaxf(mg.z, fabsf(a.z)); mg.w = fmaxf(mg.w, fabsf(a.w));
-                    mx.x = fmaxf(mx.x, fabsf((xx.x - mu.x) * is.x)); mx.y = fmaxf(mx.y, fabsf((xx.y - mu.y) * is.y));
-                    mx.z = fmaxf(mx.z, fabsf((xx.z - mu.z) * is.z)); mx.w = fmaxf(mx.w, fabsf((xx.w - mu.w) * is.w));
+                    mx.x = fmaxf(mx.x, fabsf(xh.x)); mx.y = fmaxf(mx.y, fabsf(xh.y)); mx.z = fmaxf(mx.z, fabsf(xh.z)); mx.w = fmaxf(mx.w, fabsf(xh.w));
                 }
             };
             int r = r0 + rl;
-            for (; r + 3 * rpp < r1; r += 4 * rpp) { acc1(r); acc1(r + rpp); acc1(r + 2 * rpp); acc1(r + 3 * rpp); }
-            for (; r < r1; r += rpp) acc1(r);
+            for (; r + 3 * rpp < r1; r += 4 * rpp) {
+                float4 qa[4], qa2[4], qx[4], qy[4];
+                unsigned m[4] = {15u, 15u, 15u, 15u};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long row = r + u * rpp;
+                    qa[u] = *reinterpret_cast<const float4*>(op.dy + row * op.lddy + c0);
+                    if (HAS2) qa2[u] = *reinterpret_cast<const float4*>(op.dy2 + row * op.lddy2 + c0);
+                    qx[u] = *reinterpret_cast<const float4*>(op.x + row * op.ldx + c0);
+                    if (RM == 3) qy[u] = *reinterpret_cast<const float4*>(op.y + row * op.ldy + c0);
+                    if (RM == 1) m[u] = op.mask[row * op.c4 + cc];
+                }
+                __builtin_amdgcn_sched_barrier(0);       // every load of the four rows is in flight before the first use
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fold(qa[u], HAS2 ? qa2[u] : qa[u], qx[u], RM == 3 ? qy[u] : qx[u], m[u]);
+            }
+            for (; r < r1; r += rpp) {
+                const long long row = r;
+                const float4 qa = *reinterpret_cast<const float4*>(op.dy + row * op.lddy + c0);
+                const float4 qa2 = HAS2 ? *reinterpret_cast<const float4*>(op.dy2 + row * op.lddy2 + c0) : qa;
+                const float4 qx = *reinterpret_cast<const float4*>(op.x + row * op.ldx + c0);
+                const float4 qy = RM == 3 ? *reinterpret_cast<const float4*>(op.y + row * op.ldy + c0) : qx;
+                const unsigned m = RM == 1 ? op.mask[row * op.c4 + cc] : 15u;
+                fold(qa, qa2, qx, qy, m);
+            }
         }
         const int ncol = tpr * 4;
         for (int pass = 0; pass < (cmax ? 2 : 1); ++pass) {
@@ -835,9 +874,14 @@ extern "C" int glf_bn_bwd(const float* dy, int lddy, const float* x, int ldx, co
         // two launches: reduction with atomics into the caller's ZERO-FILLED buffer (2 c doubles, then 2 c floats of maxima), apply
         float* fmax = reinterpret_cast<float*>(fused_sums + (size_t)2 * c);
         const int fs = fused_slices(rows, c);
-        const int c4 = c / 4, tpr = c4 < RT ? c4 : RT;
-        hipLaunchKernelGGL(bnbwd_reduce_atomic_kernel, dim3(fs, (c4 + tpr - 1) / tpr), dim3(RT), 0, glf::S(s), op, rows, c, fs, fused_sums,
-                           packed_dx ? fmax : (float*)nullptr);
+        const int c4 = c / 4, tpr = c4 < FUSED_TPR ? c4 : FUSED_TPR;
+        const dim3 rgrid(fs, (c4 + tpr - 1) / tpr);
+        float* rmax = packed_dx ? fmax : (float*)nullptr;
+        const int rm = !op.relu ? 0 : (op.mask ? 1 : (op.y ? 3 : 2));
+#define GLF_BNR(H2, RM_) hipLaunchKernelGGL((bnbwd_reduce_atomic_kernel<H2, RM_>), rgrid, dim3(RT), 0, glf::S(s), op, rows, c, fs, fused_sums, rmax)
+        if (op.dy2) { if (rm == 0) GLF_BNR(true, 0); else if (rm == 1) GLF_BNR(true, 1); else if (rm == 2) GLF_BNR(true, 2); else GLF_BNR(true, 3); }
+        else { if (rm == 0) GLF_BNR(false, 0); else if (rm == 1) GLF_BNR(false, 1); else if (rm == 2) GLF_BNR(false, 2); else GLF_BNR(false, 3); }
+#undef GLF_BNR
         if (int rc = glf::check_launch("bn_bwd_reduce(fused)")) return rc;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(total4f, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s), dy, lddy, x, ldx, y, ldy,
                            Coef{mean, invstd, gamma, beta}, (const float*)nullptr, (const float*)nullptr, dx, lddx, dres, lddres, total4f, c / 4, relu, training,

@@ -61,16 +61,23 @@ __device__ __forceinline__ float bn_val(float x, float mu, float is, float ga, f
 // ----------------------------------------------------------------------------------------------------------------------
 constexpr int RT = 256;
 
-__host__ __device__ inline int red_slices(int rows, int c) {
+// Grid shape of the column reductions (profiles/r04_bn_reduce_sweep.txt): a workgroup covers RED_TPR * 8 columns with 256 / RED_TPR row
+// lanes that are folded in LDS, 16 rows per thread, at most 1 024 workgroups.  What it optimises is the number of f64 atomics that
+// land on ONE address: same-address atomics are serialised by the L2 (~25-30 ns each; 1 024 workgroups adding to the same 512
+// doubles took longer than streaming the tensor), so narrow column blocks -- many blocks, few row slices per block -- beat whole
+// rows: 193 600 x 256: 37.8 -> 27.5 us, 50 176 x 1 024: 45.4 -> 20.3 us.  More, smaller workgroups only add atomics.
+constexpr int g_red_rpt = 16, g_red_cap = 1024, g_red_tpr = 16;
+inline void red_init() {}
+inline int red_slices(int rows, int c) {
     // A workgroup streams `per` rows of all its channels; the grid must put enough loads in flight to reach the HBM rate (these
     // reductions are latency-bound at low occupancy: 512 workgroups of 12 dependent iterations each ran at 1 TB/s), so: ~64 rows
     // per row lane, at most 1 024 workgroups (one f64 atomic per column and slice).
     const int c8 = c > 8 ? c / 8 : 1;
-    const int tpr = c8 < 256 ? c8 : 256;
+    const int tpr = c8 < g_red_tpr ? c8 : g_red_tpr;
     const int rpp = 256 / tpr;                        // rows per pass of a workgroup
-    int s = (rows + 16 * rpp - 1) / (16 * rpp);       // 16 rows per thread
+    int s = (rows + g_red_rpt * rpp - 1) / (g_red_rpt * rpp);
     const int cblocks = (c8 + tpr - 1) / tpr;
-    int cap = 1024 / cblocks;
+    int cap = g_red_cap / cblocks;
     if (cap < 1) cap = 1;
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
@@ -79,11 +86,11 @@ __host__ __device__ inline int red_slices(int rows, int c) {
 // sums over its <= ~16-64 rows, four rows' loads in flight at a time; the row lanes of a workgroup are folded in double through LDS
 // and ONE f64 atomic per column, statistic and workgroup reaches memory.
 template <class Op>
-__global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ sums) {
+__global__ __launch_bounds__(RT) void s16_colreduce_kernel(Op op, int rows, int c, int slices, double* __restrict__ sums, int tpr_max) {
     __shared__ float sh[RT * 16];
     const int tid = threadIdx.x;
     const int c8 = c >> 3;
-    const int tpr = c8 < RT ? c8 : RT;            // threads per row
+    const int tpr = c8 < tpr_max ? c8 : tpr_max;  // threads per row
     const int rpp = RT / tpr;                     // rows per pass
     const int ct = tid % tpr, rl = tid / tpr;
     const int slice = blockIdx.x;
@@ -171,6 +178,105 @@ struct OpBnBwd16 {          // (dy', dy' * xhat), dy' = (dy + dy2) * relu-mask
     }
 };
 
+__device__ __forceinline__ F8 unpack8(const uint4 q) {
+    F8 o;
+    o.v[0] = __uint_as_float(q.x << 16); o.v[1] = __uint_as_float(q.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(q.y << 16); o.v[3] = __uint_as_float(q.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(q.z << 16); o.v[5] = __uint_as_float(q.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(q.w << 16); o.v[7] = __uint_as_float(q.w & 0xffff0000u);
+    return o;
+}
+
+// BatchNorm backward column reduce, the form that runs: the generic kernel above with OpBnBwd16 compiled into a chain of dependent
+// loads (dy -> wait -> dy2 -> wait -> x -> wait -> mask -> the four coefficient vectors again for every row: the ISA had five
+// s_waitcnt vmcnt(0) per row and 2.3 TB/s).  Here the coefficient vectors are loaded once per column block, the loads of FOUR rows
+// (8-12 x 16 bytes per lane) are issued back to back with nothing between them, and the arithmetic follows.
+// HAS2: a second gradient addend; RM: 0 = no ReLU, 1 = sign bytes, 2 = sign recomputed from x and the BatchNorm coefficients.
+template <bool HAS2, int RM>
+__global__ __launch_bounds__(RT) void s16_bnbwd_reduce_kernel(OpBnBwd16 op, int rows, int c, int slices, double* __restrict__ sums, int tpr_max) {
+    __shared__ float sh[RT * 16];
+    const int tid = threadIdx.x;
+    const int c8 = c >> 3;
+    const int tpr = c8 < tpr_max ? c8 : tpr_max;
+    const int rpp = RT / tpr;
+    const int ct = tid % tpr, rl = tid / tpr;
+    const int slice = blockIdx.x;
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = slice * per, r1 = min(rows, r0 + per);
+    for (int cb = blockIdx.y * tpr; cb < c8; cb += gridDim.y * tpr) {
+        const int cc = cb + ct;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        if (cc < c8 && rl < rpp) {
+            const int c0 = cc * 8;
+            const F8 mu = ldf8(op.mean + c0), is = ldf8(op.invstd + c0);
+            F8 ga = mu, be = mu;
+            if (RM == 2) { ga = ldf8(op.gamma + c0); be = ldf8(op.beta + c0); }
+            auto fold = [&](const uint4 qg, const uint4 qg2, const uint4 qx, unsigned m) __attribute__((always_inline)) {
+                F8 g = unpack8(qg);
+                if (HAS2) {
+                    const F8 g2 = unpack8(qg2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g.v[j] += g2.v[j];
+                }
+                const F8 xx = unpack8(qx);
+                if (RM == 2) {
+                    m = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m |= (bn_val(xx.v[j], mu.v[j], is.v[j], ga.v[j], be.v[j]) > 0.f ? 1u : 0u) << j;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (RM == 0 || ((m >> j) & 1u)) ? g.v[j] : 0.f;
+                    acc[j] += gj;
+                    acc[8 + j] += gj * (xx.v[j] - mu.v[j]) * is.v[j];
+                }
+            };
+            int r = r0 + rl;
+            for (; r + 3 * rpp < r1; r += 4 * rpp) {
+                uint4 qg[4], qg2[4], qx[4];
+                unsigned m[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long row = r + u * rpp;
+                    qg[u] = *reinterpret_cast<const uint4*>(op.dy + row * op.lddy + c0);
+                    if (HAS2) qg2[u] = *reinterpret_cast<const uint4*>(op.dy2 + row * op.lddy2 + c0);
+                    qx[u] = *reinterpret_cast<const uint4*>(op.x + row * op.ldx + c0);
+                    if (RM == 1) m[u] = op.mask[row * op.c8 + cc];
+                }
+                __builtin_amdgcn_sched_barrier(0);       // all loads of the four rows are in flight before the first use (hipcc sinks them to their uses)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fold(qg[u], HAS2 ? qg2[u] : qg[u], qx[u], m[u]);
+            }
+            for (; r < r1; r += rpp) {
+                const long long row = r;
+                const uint4 qg = *reinterpret_cast<const uint4*>(op.dy + row * op.lddy + c0);
+                const uint4 qg2 = HAS2 ? *reinterpret_cast<const uint4*>(op.dy2 + row * op.lddy2 + c0) : qg;
+                const uint4 qx = *reinterpret_cast<const uint4*>(op.x + row * op.ldx + c0);
+                const unsigned m = RM == 1 ? op.mask[row * op.c8 + cc] : 0xffu;
+                fold(qg, qg2, qx, m);
+            }
+        }
+        const int ncol = tpr * 8;
+        if (rl < rpp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sh[(0 * rpp + rl) * ncol + ct * 8 + j] = acc[j]; sh[(1 * rpp + rl) * ncol + ct * 8 + j] = acc[8 + j]; }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * ncol; idx += RT) {
+            const int st = idx / ncol, col = idx - st * ncol;
+            const int gc = cb * 8 + col;
+            if (gc < c) {
+                double d = 0;
+                for (int q = 0; q < rpp; ++q) d += sh[(st * rpp + q) * ncol + col];
+                atomicAdd(sums + st * c + gc, d);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct OpColsum16 {         // (dy, 0)
     const u16* dy; int ld;
     __device__ void operator()(int r, int c, float* a, float* b) const {
@@ -182,10 +288,24 @@ struct OpColsum16 {         // (dy, 0)
 
 template <class Op>
 int launch_colreduce16(Op op, int rows, int c, double* sums, hipStream_t s) {
+    red_init();
     const int slices = red_slices(rows, c);
-    const int c8 = c / 8, tpr = c8 < RT ? c8 : RT;
-    hipLaunchKernelGGL((s16_colreduce_kernel<Op>), dim3(slices, (c8 + tpr - 1) / tpr), dim3(RT), 0, s, op, rows, c, slices, sums);
+    const int c8 = c / 8, tpr = c8 < g_red_tpr ? c8 : g_red_tpr;
+    hipLaunchKernelGGL((s16_colreduce_kernel<Op>), dim3(slices, (c8 + tpr - 1) / tpr), dim3(RT), 0, s, op, rows, c, slices, sums, g_red_tpr);
     return glf::check_launch("s16_colreduce");
+}
+
+int launch_bnbwd_reduce16(const OpBnBwd16& op, int rows, int c, double* sums, hipStream_t s) {
+    red_init();
+    const int slices = red_slices(rows, c);
+    const int c8 = c / 8, tpr = c8 < g_red_tpr ? c8 : g_red_tpr;
+    const dim3 grid(slices, (c8 + tpr - 1) / tpr), block(RT);
+    const int rm = !op.relu ? 0 : (op.mask ? 1 : 2);
+#define GLF_BNR(H2, RM_) hipLaunchKernelGGL((s16_bnbwd_reduce_kernel<H2, RM_>), grid, block, 0, s, op, rows, c, slices, sums, g_red_tpr)
+    if (op.dy2) { if (rm == 0) GLF_BNR(true, 0); else if (rm == 1) GLF_BNR(true, 1); else GLF_BNR(true, 2); }
+    else { if (rm == 0) GLF_BNR(false, 0); else if (rm == 1) GLF_BNR(false, 1); else GLF_BNR(false, 2); }
+#undef GLF_BNR
+    return glf::check_launch("s16_bn_bwd_reduce");
 }
 
 __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
@@ -767,7 +887,7 @@ extern "C" int glf_s16_bn_bwd(const void* dy, int lddy, const void* dy2, int ldd
     if (dy2) { REQ_AL(dy2, "dy2"); REQ_LD(lddy2, "lddy2"); }
     const OpBnBwd16 op{static_cast<const u16*>(dy), lddy, static_cast<const u16*>(dy2), lddy2, static_cast<const u16*>(x), ldx, mean, invstd, gamma, beta,
                        relu, relu_mask, c / 8};
-    if (int rc = launch_colreduce16(op, rows, c, sums, glf::S(s))) return rc;
+    if (int rc = launch_bnbwd_reduce16(op, rows, c, sums, glf::S(s))) return rc;
     const long long total8 = (long long)rows * (c / 8);
     hipLaunchKernelGGL(s16_bnbwd_apply_kernel, dim3(stream_grid(total8, 256)), dim3(256), (size_t)2 * c * sizeof(float), glf::S(s),
                        static_cast<const u16*>(dy), lddy, static_cast<const u16*>(dy2), lddy2, static_cast<const u16*>(x), ldx, mean, invstd, gamma, beta,

@@ -7,8 +7,8 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-groups = [("NT contractions", r"gemm_rows"), ("TN contractions (wgrad)", r"gemm_tn"), ("tn_reduce", r"tn_reduce"),
-          ("BN bwd reduce", r"colreduce_kernel<.*OpBnBwd|bnbwd_reduce"), ("BN bwd apply", r"bn_bwd_apply"), ("BN apply", r"bn_apply_kernel"),
+groups = [("NT contractions", r"gemm_rows|s16_rows_kernel|gemm_skinny"), ("TN contractions (wgrad)", r"gemm_tn|s16_tn_kernel"), ("tn_reduce", r"tn_reduce"),
+          ("BN bwd reduce", r"colreduce_kernel<.*OpBnBwd|bnbwd_reduce"), ("BN bwd apply", r"bn_bwd_apply|bnbwd_apply"), ("BN apply", r"bn_apply_kernel|bn_apply_sums"),
           ("BN stats / finalize", r"colreduce_kernel<.*OpStats|bn_stats_finalize|sum_finalize|bnbwd_finalize"),
           ("other column reduces", r"colreduce"), ("add_n (fan-in)", r"add_n"), ("split_packed", r"split_packed"),
           ("weights refresh", r"weights_refresh"), ("bn_res_ln", r"bn_res_ln"), ("stem", r"stem"), ("maxpool", r"maxpool"),

@@ -17,6 +17,9 @@ if has ks; then
     # (a) the bench's own launch mode (eager step, side streams on): the kernel durations the bench line's roofline is checked against
     timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/ks1_$prec -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 5 --warmup 2 $COMMON > /tmp/ks1_$prec.log 2>&1 || { tail -3 /tmp/ks1_$prec.log; exit 1; }
     cp $(find /tmp/ks1_$prec -name "*kernel_stats.csv" | head -1) $O/r04_bench_c2_${prec}_kernel_stats.csv
+    # where the GPU's time goes during a step of the timed mode: steps 2 .. 5 of the command's 2 warm-up + 5 timed steps
+    python3 $R/profiles/ubench/timeline.py $(find /tmp/ks1_$prec -name "*kernel_trace.csv" | head -1) 4 2 > $O/r04_timeline_step_$prec.txt
+    head -4 $O/r04_timeline_step_$prec.txt
     # (b) one stream: per-kernel time without overlap (the denominators of the per-kernel tables in DESIGN.md)
     GLF_STREAMS=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/ks0_$prec -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 5 --warmup 2 $COMMON > /tmp/ks0_$prec.log 2>&1 || { tail -3 /tmp/ks0_$prec.log; exit 1; }
     cp $(find /tmp/ks0_$prec -name "*kernel_stats.csv" | head -1) $O/r04_bench_c2_${prec}_one_stream_kernel_stats.csv

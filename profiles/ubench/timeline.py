@@ -20,7 +20,7 @@ if first + nsteps >= len(marks):
     print("not enough step markers after", first, ":", len(marks)); sys.exit(1)
 lo, hi = marks[first], marks[first + nsteps]
 sel = [(s, e, n) for s, e, n in rows if s >= lo and s < hi]
-is_gemm = lambda n: bool(re.search(r"gemm_rows|gemm_tn_|attn_", n))
+is_gemm = lambda n: bool(re.search(r"gemm_rows|gemm_tn_|attn_|s16_rows_kernel|s16_tn_kernel", n))
 ev = []
 for s, e, n in sel:
     g = 1 if is_gemm(n) else 0

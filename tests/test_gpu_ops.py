@@ -698,6 +698,26 @@ def test_conv_bn_backward_with_packed_gradient_matches_fp32_gradient_path(cfg):
         _ops.set_precision("f32")
 
 
+def test_colmax_is_refused_where_no_epilogue_folds_it():
+    """glf_gemm_params.colmax exists in the wide-store epilogue of the split-fp16 NT kernels only; a call that would run any other
+    epilogue (exact fp32 kernels, an unaligned C) fails with GLF_ERR_UNSUPPORTED instead of leaving the maxima at zero."""
+    from glfusion_amd import ops as _ops
+    rows, c, k = 300, 64, 64
+    a, b = rnd(rows, k, seed=1).to(DEV), rnd(c, k, seed=2).to(DEV)
+    for precision, ldc, ok in (("f16x3", c, True), ("f32", c, False), ("f16x3", c + 2, False)):
+        _ops.set_precision(precision)
+        try:
+            x = torch.empty(rows, ldc, device=DEV)
+            sums, colmax = _ops.stats_slot(c, DEV), _ops.colmax_slot(c, DEV)
+            if ok:
+                _ops.gemm("nt", a, b, x, M=rows, N=c, K=k, lda=k, ldb=k, ldc=ldc, colstats=sums, colmax=colmax)
+            else:
+                with pytest.raises(RuntimeError, match="colmax|colstats"):
+                    _ops.gemm("nt", a, b, x, M=rows, N=c, K=k, lda=k, ldb=k, ldc=ldc, colstats=sums, colmax=colmax)
+        finally:
+            _ops.set_precision("f32")
+
+
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("shape,k", [((3, 9, 11, 64), 64), ((2, 7, 5, 512), 256), ((1, 33, 17, 128), 1152)])
 def test_bn_forward_writes_packed_activation(relu, shape, k):
