@@ -150,6 +150,10 @@ class Trainer:
         if not torch.cuda.is_available():
             raise RuntimeError("glfusion_amd.engine.Trainer needs an MI355X: the HIP engine has no CPU fallback")
         self.print_val = tr.get("global_rank", 0) == 0                       # main.py:92
+        # config['train']['precision'] (no reference counterpart): "f32" | "bf16x6" | "f16x3" | "f16" | "bf16" (16-bit activation storage,
+        # BASELINE.json configs[2] / [4]); absent = whatever glfusion_amd.ops is set to
+        if tr.get("precision"):
+            ops.set_precision(tr["precision"])
         self.model = Global_and_Local(view_num=self.view_num).to(self.device)  # main.py:150
         opt = config["net"]["opt"]
         if opt.get("opt_name", "Adam") != "Adam":

@@ -82,11 +82,25 @@ def test_training_step_with_cycle_loss_and_adam_vs_oracle():
     assert n_off <= 0.01 * n_el, (n_off, n_el)
 
 
-def test_trainer_surface_runs_cycle_training_and_checkpoints(tmp_path):
+@pytest.mark.parametrize("precision", [None, "bf16"])
+def test_trainer_surface_runs_cycle_training_and_checkpoints(tmp_path, precision):
+    """precision "bf16": the same Trainer surface in 16-bit storage mode (config['train']['precision']) -- seg + cycle loss, fused
+    Adam on fp32 master weights, reference-format checkpoint, eval harness."""
+    from glfusion_amd import ops
     from glfusion_amd.engine import Trainer
     cfg = {"train": {"batch_size": 2, "num_epochs": 1, "clip_length": 29, "view_num": ["1"], "test_view": ["1"], "dense_cyc": True,
                      "save_dir": str(tmp_path), "iters_per_epoch": 1, "global_rank": 0},
            "net": {"opt": {"opt_name": "Adam", "lr": 3e-4, "params": (0.9, 0.999), "weight_decay": 1e-5}}}
+    if precision:
+        cfg["train"]["precision"] = precision
+    try:
+        _trainer_surface(cfg, tmp_path)
+    finally:
+        ops.set_precision("f32")
+
+
+def _trainer_surface(cfg, tmp_path):
+    from glfusion_amd.engine import Trainer
     t = Trainer(cfg)
     before = t.model.classifier["1"][4].weight.detach().clone()
     t.train(is_backbone=False, is_cycle=True)
@@ -235,7 +249,7 @@ def test_weights_refresh_is_bit_identical_to_per_tensor_rebuild():
         ops.set_precision("f32")
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
 def test_step_graph_replay_matches_eager_step(prec):
     """engine.StepGraph: the step recorded as ONE hipGraph gives the eager step's loss and gradients; a replay after the fused
     Adam wrote the parameters sees the new weights (the weight-image refresh is part of the recorded work); Dropout draws a new
@@ -283,7 +297,9 @@ def test_step_graph_replay_matches_eager_step(prec):
             # Adam's first update moves every weight by +-lr whatever its gradient's size, so entries whose gradient is rounding
             # noise move in run-dependent directions and the second steps of two RUNS separate; k = 1 only has to show that the
             # replay saw the updated weights (the loss moved by far more than the tolerance) -- step 0 is the tight comparison
-            assert abs(loss - want[k][0]) <= (1e-6 if k == 0 else 1e-3) * abs(want[k][0]), (k, loss, want[k][0])
+            # (bf16: two runs of the same step differ where an f64-atomic sum's last bit flips a bf16 rounding downstream -- the
+            # replay is compared at the mode's own run-to-run noise, not at fp32's)
+            assert abs(loss - want[k][0]) <= ((2e-4 if prec == "bf16" else 1e-6) if k == 0 else 1e-3) * abs(want[k][0]), (k, loss, want[k][0])
             if k == 1:
                 assert abs(want[1][0] - want[0][0]) > 5e-3 * abs(want[0][0]), "the test's update is too small to tell stale weights"
                 break
@@ -297,6 +313,8 @@ def test_step_graph_replay_matches_eager_step(prec):
                     # (the ASPP pooled branch normalises N = 4 frame averages per channel: ill-conditioned -- the float-atomic
                     # noise of two RUNS of the same eager step already moves its gradients by ~1e-3)
                     rel = 1e-2 if ".convs.4." in names[i] else 1e-3
+                    if prec == "bf16":
+                        rel = 0.5 if ".convs.4." in names[i] else 5e-2
                     assert err <= rel * float(ref.norm()) + floor, (k, names[i], err, float(ref.norm()), floor)
                 else:
                     assert p.grad is None
