@@ -69,6 +69,27 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
     }
 }
 
+// the same with strides: src[b][r][c] at src + b * bs_src + r * ld_src + c; dst[b][c][r] at dst + b * bs_dst + c * ld_dst + r for
+// r < rows_pad, ZERO for rows <= r < rows_pad (a reduction dimension padded to the contraction kernels' K granule)
+__global__ __launch_bounds__(256) void transpose2d_strided_kernel(const float* __restrict__ src, long long ld_src, long long bs_src,
+                                                                  float* __restrict__ dst, long long ld_dst, long long bs_dst, int rows, int cols,
+                                                                  int rows_pad) {
+    __shared__ float tile[32][33];
+    const float* sb = src + (long long)blockIdx.z * bs_src;
+    float* db = dst + (long long)blockIdx.z * bs_dst;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? sb[(long long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows_pad) db[(long long)c * ld_dst + r] = tile[tx][i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // stem 7x7, Cin = 1.  One workgroup = 16x16 output pixels; the 22x22 input patch and the
 // 49 x Cout weights sit in LDS; each thread owns one pixel x 16 output channels per pass.
@@ -415,9 +436,9 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
     for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
     return r;
 }
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int cols) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int cols, int ld) {
     __shared__ float sh[4];
-    float* row = x + (long long)blockIdx.x * cols;
+    float* row = x + (long long)blockIdx.x * ld;
     float m = -INFINITY;
     for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, row[i]);
     m = block_reduce(m, true, sh);
@@ -426,15 +447,17 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
     s = block_reduce(s, false, sh);
     const float inv = 1.0f / s;
     for (int i = threadIdx.x; i < cols; i += 256) row[i] *= inv;
+    for (int i = cols + threadIdx.x; i < ld; i += 256) row[i] = 0.f;          // padding columns of a row stride > cols read as zero probabilities
 }
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int cols) {
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int cols, int ld) {
     __shared__ float sh[4];
-    const float* pr = p + (long long)blockIdx.x * cols;
-    float* dr = dp + (long long)blockIdx.x * cols;
+    const float* pr = p + (long long)blockIdx.x * ld;
+    float* dr = dp + (long long)blockIdx.x * ld;
     float s = 0.f;
     for (int i = threadIdx.x; i < cols; i += 256) s += pr[i] * dr[i];
     s = block_reduce(s, false, sh);
     for (int i = threadIdx.x; i < cols; i += 256) dr[i] = pr[i] * (dr[i] - s);
+    for (int i = cols + threadIdx.x; i < ld; i += 256) dr[i] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -567,6 +590,17 @@ extern "C" int glf_transpose2d(const float* src, float* dst, int rows, int cols,
     GLF_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && (rows + 31) / 32 <= 65535, GLF_ERR_BAD_SHAPE, "transpose2d: bad shape");
     hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, glf::S(s), src, dst, rows, cols);
     return glf::check_launch("transpose2d");
+}
+
+extern "C" int glf_transpose2d_strided(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,
+                                       int64_t batch_stride_dst, int rows, int cols, int rows_pad, int batch, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(src && dst, GLF_ERR_NULL, "transpose2d_strided: null argument");
+    GLF_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && rows_pad >= rows && (rows_pad + 31) / 32 <= 65535 && ld_src >= cols &&
+                ld_dst >= rows_pad, GLF_ERR_BAD_SHAPE, "transpose2d_strided: bad shape");
+    hipLaunchKernelGGL(transpose2d_strided_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32, batch), dim3(256), 0, glf::S(s), src, (long long)ld_src,
+                       (long long)batch_stride_src, dst, (long long)ld_dst, (long long)batch_stride_dst, rows, cols, rows_pad);
+    return glf::check_launch("transpose2d_strided");
 }
 
 extern "C" int glf_stem7x7_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -893,14 +927,28 @@ extern "C" int glf_softmax_rows(float* x, int64_t rows, int cols, glf_stream_t s
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(x, GLF_ERR_NULL, "softmax_rows: null argument");
     GLF_REQUIRE(rows > 0 && rows < 2147483647LL && cols > 0, GLF_ERR_BAD_SHAPE, "softmax_rows: bad shape");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), x, cols);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), x, cols, cols);
     return glf::check_launch("softmax_rows");
+}
+extern "C" int glf_softmax_rows_ld(float* x, int64_t rows, int cols, int ld, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(x, GLF_ERR_NULL, "softmax_rows_ld: null argument");
+    GLF_REQUIRE(rows > 0 && rows < 2147483647LL && cols > 0 && ld >= cols, GLF_ERR_BAD_SHAPE, "softmax_rows_ld: bad shape");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), x, cols, ld);
+    return glf::check_launch("softmax_rows_ld");
+}
+extern "C" int glf_softmax_rows_bwd_ld(const float* p, float* dp_inout, int64_t rows, int cols, int ld, glf_stream_t s) {
+    if (int rc = glf::ensure_init()) return rc;
+    GLF_REQUIRE(p && dp_inout, GLF_ERR_NULL, "softmax_rows_bwd_ld: null argument");
+    GLF_REQUIRE(rows > 0 && rows < 2147483647LL && cols > 0 && ld >= cols, GLF_ERR_BAD_SHAPE, "softmax_rows_bwd_ld: bad shape");
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), p, dp_inout, cols, ld);
+    return glf::check_launch("softmax_rows_bwd_ld");
 }
 extern "C" int glf_softmax_rows_bwd(const float* p, float* dp_inout, int64_t rows, int cols, glf_stream_t s) {
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(p && dp_inout, GLF_ERR_NULL, "softmax_rows_bwd: null argument");
     GLF_REQUIRE(rows > 0 && rows < 2147483647LL && cols > 0, GLF_ERR_BAD_SHAPE, "softmax_rows_bwd: bad shape");
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), p, dp_inout, cols);
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, glf::S(s), p, dp_inout, cols, cols);
     return glf::check_launch("softmax_rows_bwd");
 }
 

@@ -272,6 +272,11 @@ int glf_tap_major_to_oihw(const float* w, float* out, int cout, int cin, int tap
 int glf_oihw_to_tap_major_t(const float* w, float* out, int cout, int cin, int taps, glf_stream_t s);
 /* batched 2-D transpose dst[b][c][r] = src[b][r][c] (operand re-layout for NT contractions). */
 int glf_transpose2d(const float* src, float* dst, int rows, int cols, int batch, glf_stream_t s);
+/* The same with strides: src[b][r][c] = src[b * batch_stride_src + r * ld_src + c]; dst[b][c][r] (row stride ld_dst) for r < rows,
+ * ZERO for rows <= r < rows_pad: a column slice of a wider matrix transposed into an operand whose reduction dimension is padded to
+ * the contraction kernels' K granule (the g^T / phi^T operands of the per-frame softmax attention, fusion.py). */
+int glf_transpose2d_strided(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,
+                            int64_t batch_stride_dst, int rows, int cols, int rows_pad, int batch, glf_stream_t s);
 
 /* ---------------------------------------------------------------------------------------
  * Multi-tensor weight refresh.  Everything the contraction kernels derive from the parameters -- tap-major re-layouts
@@ -581,6 +586,10 @@ int glf_bn_res_ln_bwd(const float* dz, const float* w, const float* x, const flo
  * ds = p * (dp - sum(dp*p)). */
 int glf_softmax_rows(float* x, int64_t rows, int cols, glf_stream_t s);
 int glf_softmax_rows_bwd(const float* p, float* dp_inout, int64_t rows, int cols, glf_stream_t s);
+/* The same over rows of stride ld >= cols; the padding columns [cols, ld) are written as zeros (zero probabilities / zero score
+ * gradients: the matrices then serve as contraction operands with K = ld). */
+int glf_softmax_rows_ld(float* x, int64_t rows, int cols, int ld, glf_stream_t s);
+int glf_softmax_rows_bwd_ld(const float* p, float* dp_inout, int64_t rows, int cols, int ld, glf_stream_t s);
 /* F.interpolate(mode='bilinear', align_corners=False) (ours.py:1838,1841): x [N][h][w][C]
  * channels-last -> y [N][C][H][W] (NCHW, what the caller's loss consumes), and its adjoint. */
 int glf_bilinear_up_fwd(const float* x, float* y, int n, int h, int w, int c, int ho, int wo, glf_stream_t s);
