@@ -25,10 +25,38 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import AttnParams, check, lib
 from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry, WJ_COPY, stats_slot, amax_of, amax_slot, colsum, gemm, set_amax, split_mode,
-                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, packed_hit, pick, zeros)
+                  tn_needs_zero, transpose2d, weight_T, weight_packed, nt_presplit_ok, tn_presplit_ok, act_packed, packed_hit, pick, zeros, _ones4)
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
+# 'embedded' under the split 16-bit contraction precisions: scores per group of frames through the split-fp16 MFMA kernels (QK^T, PV,
+# dP, dS^T theta, dS phi, P^T dY as plain contractions, softmax statistics in fp32, at most CHUNK_BYTES of scores alive) instead of
+# the fused exact-fp32 kernel -- 3-4x its rate at the model's shapes; 0 = the fused kernel under every precision
+CHUNKED_SOFTMAX = os.environ.get("GLF_CHUNKED_SOFTMAX", "1") != "0"
+CHUNK_BYTES = int(os.environ.get("GLF_SOFTMAX_CHUNK_BYTES", str(2 << 30)))
+
+
+def chunked_softmax_ok(ci: int, L: int) -> bool:
+    return CHUNKED_SOFTMAX and split_mode() and ci % 32 == 0 and L % 4 == 0
+
+
+def _frames_per_chunk(n: int, L: int) -> int:
+    lp = (L + 31) // 32 * 32
+    return max(1, min(n, CHUNK_BYTES // (L * lp * 4)))
+
+
+def _scores(th, ph, f0, g, L, lp, ci, c3, am_q, S):
+    """S[0:g] = softmax_rows(theta_f phi_f^T) for frames f0 .. f0 + g: rows of stride lp (a multiple of 32: the matrices are K
+    operands of the next contractions), padding columns zero."""
+    bq = L * c3
+    gemm("nt", th[f0 * L:], ph[f0 * L:], S, M=L, N=L, K=ci, lda=c3, ldb=c3, ldc=lp, batch=g, bsa=bq, bsb=bq, bsc=L * lp,
+         amax_a=am_q, amax_b=am_q)
+    check(lib.glf_softmax_rows_ld(_p(S), g * L, L, lp, _stream()), "softmax_rows_ld")
+
+
+def _transposed(src, f0, g, L, lp, ci, c3, out):
+    """out[0:g] = the [ci, lp] transposes of the [L, ci] column slices src (row stride c3) of frames f0 .. f0 + g, zero beyond L."""
+    check(lib.glf_transpose2d_strided(_p(src[f0 * L:]), c3, L * c3, _p(out), lp, ci * lp, L, ci, lp, g, _stream()), "transpose2d_strided")
 PACKED_TPAVI = os.environ.get("GLF_PACKED_TPAVI", "1") != "0"      # W_z's output gradient handed over as a packed image (train mode)
 
 
@@ -134,6 +162,24 @@ class TpaviFn(Function):
                 del attT
             else:
                 gemm("nn", th, att, y, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=ci, batch=n, bsa=bq, bsb=ci * ci, bsc=L * ci)
+        elif mode == "embedded" and chunked_softmax_ok(ci, L):
+            # per group of frames: S = theta phi^T, P = softmax(S) in place, y = P g -- three launches + one transpose of g on the
+            # split-fp16 kernels; nothing of size L x L is kept (the backward pass recomputes P group by group)
+            att = torch.empty(1, **f32)
+            lp = (L + 31) // 32 * 32
+            gpc = _frames_per_chunk(n, L)
+            S = torch.empty(gpc, L, lp, **f32)
+            gT = torch.empty(gpc, ci, lp, **f32)
+            one = _ones4(dev)[:1]                                            # max P <= 1
+            am_y = amax_slot(dev)
+            for f0 in range(0, n, gpc):
+                gc = min(gpc, n - f0)
+                _scores(th, ph, f0, gc, L, lp, ci, c3, am_q, S)
+                _transposed(g, f0, gc, L, lp, ci, c3, gT)
+                gemm("nt", S, gT, y[f0 * L:], M=L, N=ci, K=lp, lda=lp, ldb=lp, ldc=ci, batch=gc, bsa=L * lp, bsb=ci * lp, bsc=L * ci,
+                     amax_a=one, amax_b=am_q, amax_c=am_y)
+            set_amax(y, am_y)
+            del S, gT
         elif mode == "embedded" and fused_softmax_ok(ci):
             # ONE kernel: 64-query blocks, key tiles through LDS, online row max / sum, P g in MFMA accumulators; the
             # [L, L] scores are never written.  `att` holds the row log-sum-exp the backward pass recomputes them against.
@@ -274,6 +320,33 @@ class TpaviFn(Function):
                 del dMT
             else:
                 gemm("nn", ph, dM, dg, M=L, N=ci, K=ci, lda=c3, ldb=ci, ldc=c3, batch=n, bsa=bq, bsb=ci * ci, bsc=bq, alpha=1.0 / L)
+        elif chunked_softmax_ok(ci, L):
+            # per group of frames: P recomputed; dP = dY g^T; dg = P^T dY; dS = P (dP - rowsum(dP P)); dtheta = dS phi; dphi = dS^T theta
+            lp = (L + 31) // 32 * 32
+            gpc = _frames_per_chunk(n, L)
+            S = torch.empty(gpc, L, lp, **f32)
+            dP = torch.empty(gpc, L, lp, **f32)
+            phT = torch.empty(gpc, ci, lp, **f32)
+            one = _ones4(dev)[:1]
+            for f0 in range(0, n, gpc):
+                gc = min(gpc, n - f0)
+                _scores(th, ph, f0, gc, L, lp, ci, c3, am_q, S)
+                am_dP = amax_slot(dev)
+                gemm("nt", dy[f0 * L:], g[f0 * L:], dP, M=L, N=L, K=ci, lda=ci, ldb=c3, ldc=lp, batch=gc, bsa=bs, bsb=bq, bsc=L * lp,
+                     amax_a=am_dy, amax_b=am_q, amax_c=am_dP)
+                gemm("tn", S, dy[f0 * L:], dg[f0 * L:], M=L, N=ci, K=L, lda=lp, ldb=ci, ldc=c3, batch=gc, bsa=L * lp, bsb=bs, bsc=bq,
+                     amax_a=one, amax_b=am_dy, amax_c=am_dq_slot)
+                check(lib.glf_softmax_rows_bwd_ld(_p(S), _p(dP), gc * L, L, lp, _stream()), "softmax_rows_bwd_ld")       # dP <- dS
+                am_dS = amax_slot(dev)                                       # |dS| <= P (|dP| + |sum dP P|) <= 2 max|dP|
+                check(lib.glf_amax_combine(_p(am_dP), None, 2.0, 0, _p(am_dS), _stream()), "amax_combine")
+                _transposed(ph, f0, gc, L, lp, ci, c3, phT)
+                gemm("nt", dP, phT, dth[f0 * L:], M=L, N=ci, K=lp, lda=lp, ldb=lp, ldc=c3, batch=gc, bsa=L * lp, bsb=ci * lp, bsc=bq,
+                     amax_a=am_dS, amax_b=am_q, amax_c=am_dq_slot)
+                gemm("tn", dP, th[f0 * L:], dph[f0 * L:], M=L, N=ci, K=L, lda=lp, ldb=c3, ldc=c3, batch=gc, bsa=L * lp, bsb=bq, bsc=bq,
+                     amax_a=am_dS, amax_b=am_q, amax_c=am_dq_slot)
+            if am_dq_slot is not None:
+                set_amax(dqkv, am_dq_slot)
+            del S, dP, phT
         elif fused_softmax_ok(ci):
             # recompute the score tiles from theta / phi and the saved row log-sum-exp: three passes (dg, dphi, dtheta), each
             # writing its slice of dqkv exactly once

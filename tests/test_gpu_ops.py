@@ -1003,6 +1003,63 @@ def test_fused_softmax_matches_materialised_path():
             assert _rel_l2(res[True][2][k], gk) <= 1e-4, k     # shift in front of a train-mode BatchNorm): rounding noise only
 
 
+def test_chunked_split_fp16_softmax_attention_matches_fused_kernel():
+    """TPAVIModule(mode='embedded') under f16x3: the per-frame-group form on the split-fp16 contraction kernels (S = theta phi^T,
+    row softmax in fp32, P g; backward with P recomputed: fusion.chunked_softmax_ok) against the fused exact-fp32 kernels, at the
+    config-2 length L = 2352 (padded to 2368 as a reduction dimension), three frames in groups of two (a ragged last group):
+    output within 5e-5, every gradient within 2e-4 relative L2."""
+    from glfusion_amd import fusion, ops as _ops
+    from glfusion_amd.models import TPAVIModule
+    from oracle import glfusion_ref as orc
+    res = {}
+    _ops.set_precision("f16x3")
+    old_bytes = fusion.CHUNK_BYTES
+    try:
+        for chunked in (True, False):
+            fusion.CHUNKED_SOFTMAX = chunked
+            fusion.CHUNK_BYTES = 2 * 2352 * 2368 * 4 + 1024         # two frames of scores per group
+            m = TPAVIModule(256, mode="embedded")
+            orc.closed_form_fill(m, salt=3)
+            m = m.to(DEV).train()
+            x = (orc.closed_form_tensor((3, 256, 3, 28, 28), 101, -1.0, 1.0) * 0.5).to(DEV).requires_grad_(True)
+            assert fusion.chunked_softmax_ok(128, 2352) == chunked and fusion._frames_per_chunk(3, 2352) == 2
+            z, _ = m(x)
+            (z * orc.closed_form_tensor(tuple(z.shape), 102, -1.0, 1.0).to(DEV)).sum().backward()
+            res[chunked] = (z.detach(), x.grad, {k: p.grad for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        fusion.CHUNKED_SOFTMAX, fusion.CHUNK_BYTES = True, old_bytes
+        _ops.set_precision("f32")
+    assert _rel_l2(res[True][0], res[False][0]) <= 5e-5
+    assert _rel_l2(res[True][1], res[False][1]) <= 2e-4
+    top = max(float(gk.norm()) for gk in res[False][2].values())
+    for k, gk in res[False][2].items():
+        if float(gk.norm()) > 1e-5 * top:
+            assert _rel_l2(res[True][2][k], gk) <= 2e-4, k
+
+
+def test_strided_transpose_and_padded_softmax():
+    """glf_transpose2d_strided (a column slice of a wider matrix -> [cols][rows_pad], zero beyond rows) and glf_softmax_rows_ld /
+    _bwd_ld (row stride > cols, padding columns written as zeros)."""
+    from glfusion_amd._lib import check, lib
+    b, rows, cols, ld, pad = 3, 45, 40, 100, 64
+    src = rnd(b, rows, ld, seed=5).to(DEV)
+    dst = torch.full((b, cols, pad), 7.0, device=DEV)
+    check(lib.glf_transpose2d_strided(src[:, :, 10:].data_ptr(), ld, rows * ld, dst.data_ptr(), pad, cols * pad, rows, cols, pad, b, None), "t")
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :, :rows], src[:, :, 10:10 + cols].transpose(1, 2)) and float(dst[:, :, rows:].abs().max()) == 0.0
+    x = rnd(37, 64, seed=6).to(DEV)
+    xs = x.clone()
+    check(lib.glf_softmax_rows_ld(xs.data_ptr(), 37, 50, 64, None), "s")
+    want = torch.softmax(x[:, :50].cpu(), -1)
+    assert close(xs[:, :50], want, 1e-6) and float(xs[:, 50:].abs().max()) == 0.0
+    dp = rnd(37, 64, seed=7).to(DEV)
+    dpc = dp.clone()
+    check(lib.glf_softmax_rows_bwd_ld(xs.data_ptr(), dpc.data_ptr(), 37, 50, 64, None), "sb")
+    p_ = want.double()
+    d_ = dp[:, :50].cpu().double()
+    assert close(dpc[:, :50], p_ * (d_ - (d_ * p_).sum(-1, keepdim=True)), 1e-6) and float(dpc[:, 50:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------ C convolution entry points
 @pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 96, 1, 1, 0, 1), (2, 55, 55, 16, 24, 3, 2, 1, 1), (2, 28, 28, 64, 32, 3, 1, 12, 12),
                                  (2, 28, 28, 64, 32, 3, 1, 24, 24), (2, 28, 28, 64, 32, 3, 1, 36, 36), (2, 28, 28, 32, 160, 3, 1, 2, 2)])
