@@ -486,6 +486,23 @@ __host__ __device__ inline int tn_rect_rows(const Geo& g, int tap, int K) {
     tap_band(kx * g.dil - g.pad, g.stride, g.ws, g.wd, xlo, xhi);
     return (K / (g.hd * g.wd)) * (yhi - ylo) * (xhi - xlo);
 }
+// rectangle mode keeps only the slabs of slices that run, tap after tap: first slab of `tap` (its number of slices in nvalid);
+// tap = -1: the total number of slabs
+__host__ __device__ inline int tn_rect_slab(const Geo& g, unsigned tap_mask, int tap, int K, int split, int& nvalid) {
+    int chunk = (K + split - 1) / split;
+    chunk = ((chunk + TK - 1) / TK) * TK;
+    int prefix = 0;
+    nvalid = 0;
+    for (unsigned mm = tap_mask; mm; mm &= mm - 1) {
+        const int t = __builtin_ctz(mm);
+        const int rows = tn_rect_rows(g, t, K);
+        int nv = (rows + chunk - 1) / chunk;
+        if (nv > split) nv = split;
+        if (t == tap) { nvalid = nv; return prefix; }
+        prefix += nv;
+    }
+    return prefix;
+}
 // r / d for 0 <= r < 2^24, d >= 1, inv = 1.f / d: one multiply, one conversion and two corrections instead of an integer division
 __device__ __forceinline__ int fdiv(int r, int d, float inv) {
     int q = (int)((float)r * inv);
@@ -756,7 +773,12 @@ __global__ __launch_bounds__(NTH, 2) void s16_tn_kernel(const S16Args args) {
     u16* __restrict__ Ch = nullptr;
     int ldc_e;
     if (args.partial) {
-        Cf = args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN);
+        if (RECT) {
+            int nv;
+            Cf = args.partial + (long long)(tn_rect_slab(args.g, p_tap_mask, tap, pK, p_split, nv) + sl) * ((long long)pM * pN);
+        } else {
+            Cf = args.partial + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * ((long long)pM * pN);
+        }
         ldc_e = pN;
     } else {
         Cf = reinterpret_cast<float*>(args.C) + (long long)bz * args.bsc + (long long)tap * p_tsb;
@@ -797,11 +819,14 @@ __global__ __launch_bounds__(256) void s16_tn_reduce_kernel(const float* __restr
     const int ntap = gridDim.y, bz = blockIdx.z;
     int chunk = (K + split - 1) / split;
     chunk = ((chunk + TK - 1) / TK) * TK;
-    const int k_rows = rect ? tn_rect_rows(g, tap, K) : K;
-    const int nvalid = min(split, (k_rows + chunk - 1) / chunk);      // slices that ran (the others returned early); 0: an empty rectangle
     const long long mn = (long long)M * N;
+    int nvalid = min(split, (K + chunk - 1) / chunk);                 // slices that ran (the others returned early)
     const float* __restrict__ src = partial + ((long long)bz * split * ntap + blockIdx.y) * mn;
-    const long long slice_stride = (long long)ntap * mn;
+    long long slice_stride = (long long)ntap * mn;
+    if (rect) {                                                       // compact slabs, tap after tap (batch 1)
+        src = partial + (long long)tn_rect_slab(g, tap_mask, tap, K, split, nvalid) * mn;
+        slice_stride = mn;
+    }
     const int n4 = N >> 2;
     const long long total = (long long)M * n4;
     const int ol = threadIdx.x % OG, sl = threadIdx.x / OG;
@@ -951,6 +976,11 @@ extern "C" int glf_s16_gemm_nt(const void* A, const void* B, const float* bias, 
 extern "C" size_t glf_s16_gemm_tn_workspace_bytes(const glf_gemm_params* p) {
     if (!p || p->split <= 1) return 0;
     const size_t ntap = (size_t)__builtin_popcount(p->tap_mask);
+    if (p->rect == 1 && p->gather == 1 && p->batch == 1 && p->hd > 0 && p->wd > 0 && p->kw > 0 && p->stride > 0) {
+        const Geo g{p->n_img, p->hs, p->ws, p->hd, p->wd, p->kh, p->kw, p->stride, p->pad, p->dil};
+        int nv;
+        return (size_t)tn_rect_slab(g, p->tap_mask, -1, p->K, p->split, nv) * (size_t)p->M * (size_t)p->N * sizeof(float);
+    }
     return (size_t)p->batch * (size_t)p->split * ntap * (size_t)p->M * (size_t)p->N * sizeof(float);
 }
 
@@ -959,8 +989,8 @@ extern "C" int glf_s16_gemm_tn(const void* A, const void* B, void* C, const glf_
     if (int rc = validate16(p, A, B, C, "s16_gemm_tn")) return rc;
     GLF_REQUIRE(p->gather != 2, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: transposed gather is not defined for the reduction form");
     GLF_REQUIRE(!p->colstats && !p->accumulate, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: colstats / accumulate are not built");
-    GLF_REQUIRE(p->rect == 0 || (p->rect == 1 && p->gather == 1 && p->split > 1), GLF_ERR_UNSUPPORTED,
-                "s16_gemm_tn: rect = 1 (per-tap rectangles) needs a forward gather and split > 1 (the slabs of taps with empty rectangles are summed as zero)");
+    GLF_REQUIRE(p->rect == 0 || (p->rect == 1 && p->gather == 1 && p->split > 1 && p->batch == 1), GLF_ERR_UNSUPPORTED,
+                "s16_gemm_tn: rect = 1 (per-tap rectangles) needs a forward gather, batch 1 and split > 1 (only the slabs of slices that run are kept)");
     GLF_REQUIRE(p->M % 8 == 0 && p->N % 8 == 0, GLF_ERR_UNSUPPORTED, "s16_gemm_tn: M and N must be multiples of 8 (got %d, %d)", p->M, p->N);
     if (p->gather) GLF_REQUIRE((long long)p->n_img * p->hd * p->wd == p->K, GLF_ERR_BAD_SHAPE, "s16_gemm_tn: K (%d rows) != n_img*hd*wd", p->K);
     S16Args a = make_args16(A, B, nullptr, C, p);

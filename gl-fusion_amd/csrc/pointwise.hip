@@ -293,6 +293,51 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
     __syncthreads();
     if (pl == 0 && c0 < c) y[(long long)n * c + c0] = scale * (sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
+// 16-byte form: 16 channel quads x 16 row lanes per workgroup, four rows' loads in flight per thread (the scalar form above walks
+// 196 dependent 4-byte loads per thread: 2.4 TB/s on the ASPP pooled branch's 411 MB maps)
+__global__ __launch_bounds__(256) void sum_rows4_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, float scale, int p, int c4) {
+    // sums in double: the ASPP pooled branch feeds these N per-frame averages to a BatchNorm over N samples, which amplifies their
+    // rounding by |mean| / spread -- the kernel is memory-bound, the wider adds are free
+    __shared__ double sh[4][256];
+    const int n = blockIdx.y;
+    const int cq = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int pl = threadIdx.x >> 4;                      // 16 row lanes
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (cq < c4) {
+        const float* base = x + (long long)n * p * ld + 4 * cq;
+        int r = pl;
+        for (; r + 48 < p; r += 64) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (long long)r * ld);
+            const float4 b = *reinterpret_cast<const float4*>(base + (long long)(r + 16) * ld);
+            const float4 d = *reinterpret_cast<const float4*>(base + (long long)(r + 32) * ld);
+            const float4 e = *reinterpret_cast<const float4*>(base + (long long)(r + 48) * ld);
+            s0 += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
+            s1 += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
+            s2 += ((double)a.z + (double)b.z) + ((double)d.z + (double)e.z);
+            s3 += ((double)a.w + (double)b.w) + ((double)d.w + (double)e.w);
+        }
+        for (; r < p; r += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (long long)r * ld);
+            s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
+        }
+    }
+    sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2; sh[3][threadIdx.x] = s3;
+    __syncthreads();
+    if (pl == 0 && cq < c4) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { s0 += sh[0][q * 16 + threadIdx.x]; s1 += sh[1][q * 16 + threadIdx.x]; s2 += sh[2][q * 16 + threadIdx.x]; s3 += sh[3][q * 16 + threadIdx.x]; }
+        const double sc = (double)scale;
+        *reinterpret_cast<float4*>(y + (long long)n * 4 * c4 + 4 * cq) = make_float4((float)(sc * s0), (float)(sc * s1), (float)(sc * s2), (float)(sc * s3));
+    }
+}
+__global__ __launch_bounds__(256) void bcast_rows4_kernel(const float* __restrict__ x, float* __restrict__ y, int ld, float scale, int p, int c4, long long total4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4); const long long row = i / c4;
+        const long long n = row / p;
+        const float4 v = *reinterpret_cast<const float4*>(x + (n * c4 + cc) * 4);
+        *reinterpret_cast<float4*>(y + row * ld + 4 * cc) = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+    }
+}
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int ld, float scale, int p, int c, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % c); const long long row = i / c;
@@ -790,7 +835,10 @@ extern "C" int glf_sum_rows_fwd(const float* dy, int lddy, float* dx, float scal
     if (int rc = glf::ensure_init()) return rc;
     GLF_REQUIRE(dy && dx, GLF_ERR_NULL, "sum_rows: null argument");
     GLF_REQUIRE(n > 0 && n <= 65535 && p > 0 && c > 0 && lddy >= c, GLF_ERR_BAD_SHAPE, "sum_rows: bad shape");
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((c + 63) / 64, n), dim3(256), 0, glf::S(s), dy, lddy, dx, scale, p, c);
+    if (c % 4 == 0 && lddy % 4 == 0 && al16(dy) && al16(dx))
+        hipLaunchKernelGGL(sum_rows4_kernel, dim3((c / 4 + 15) / 16, n), dim3(256), 0, glf::S(s), dy, lddy, dx, scale, p, c / 4);
+    else
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((c + 63) / 64, n), dim3(256), 0, glf::S(s), dy, lddy, dx, scale, p, c);
     return glf::check_launch("sum_rows");
 }
 extern "C" int glf_avgpool_fwd(const float* x, float* y, int n, int p, int c, glf_stream_t s) {
@@ -801,7 +849,10 @@ extern "C" int glf_bcast_rows_scaled(const float* x, float* y, int ldy, float sc
     GLF_REQUIRE(x && y, GLF_ERR_NULL, "bcast_rows: null argument");
     GLF_REQUIRE(n > 0 && p > 0 && c > 0 && ldy >= c, GLF_ERR_BAD_SHAPE, "bcast_rows: bad shape");
     const long long total = (long long)n * p * c;
-    hipLaunchKernelGGL(bcast_rows_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, glf::S(s), x, y, ldy, scale, p, c, total);
+    if (c % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y))
+        hipLaunchKernelGGL(bcast_rows4_kernel, dim3(stream_grid(total / 4, 256)), dim3(256), 0, glf::S(s), x, y, ldy, scale, p, c / 4, total / 4);
+    else
+        hipLaunchKernelGGL(bcast_rows_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, glf::S(s), x, y, ldy, scale, p, c, total);
     return glf::check_launch("bcast_rows");
 }
 extern "C" int glf_bcast_rows_fwd(const float* x, float* y, int ldy, int n, int p, int c, glf_stream_t s) {

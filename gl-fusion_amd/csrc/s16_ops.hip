@@ -664,12 +664,24 @@ __global__ __launch_bounds__(256) void s16_sum_rows_kernel(const u16* __restrict
     const int cg = blockIdx.x * 32 + (threadIdx.x & 31);       // group of 8 channels
     const int pl = threadIdx.x >> 5;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (cg * 8 < c)
-        for (int r = pl; r < p; r += 8) {
-            const F8 v = ld8(x + ((long long)n * p + r) * ld + cg * 8);
+    if (cg * 8 < c) {
+        const u16* base = x + (long long)n * p * ld + cg * 8;
+        int r = pl;
+        for (; r + 24 < p; r += 32) {                                   // four rows' loads in flight
+            const uint4 q0 = *reinterpret_cast<const uint4*>(base + (long long)r * ld);
+            const uint4 q1 = *reinterpret_cast<const uint4*>(base + (long long)(r + 8) * ld);
+            const uint4 q2 = *reinterpret_cast<const uint4*>(base + (long long)(r + 16) * ld);
+            const uint4 q3 = *reinterpret_cast<const uint4*>(base + (long long)(r + 24) * ld);
+            const F8 v0 = unpack8(q0), v1 = unpack8(q1), v2 = unpack8(q2), v3 = unpack8(q3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
+        }
+        for (; r < p; r += 8) {
+            const F8 v = ld8(base + (long long)r * ld);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += v.v[j];
         }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) sh[j * 256 + threadIdx.x] = s[j];
     __syncthreads();

@@ -1,4 +1,5 @@
-timeout -k 10 800 python -m pytest tests/test_gpu_ops.py tests/test_gpu_s16.py tests/test_gpu_model.py -x -q > gpurun_out/t13.log 2>&1; echo rc=$?; tail -3 gpurun_out/t13.log
+# the whole GPU suite, then the step time of both storage modes (ms per step, two alternations)
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gputests.log 2>&1; echo rc=$?; tail -3 gpurun_out/gputests.log
 b() { timeout -k 10 200 python bench.py --precision $1 --steps 6 --warmup 2 --no-exact-f32 --no-config3 --no-bf16 --no-cpu-baseline --no-other-mode --no-fusion-block 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
@@ -8,4 +9,3 @@ b bf16 "bf16"
 b f16x3 "f16x3"
 b bf16 "bf16"
 b f16x3 "f16x3"
-timeout -k 10 120 python profiles/ubench/s16_bn_probe.py 2>&1 | grep -v amdgpu.ids

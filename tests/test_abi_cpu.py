@@ -29,6 +29,27 @@ def test_header_parses_and_library_exports_every_symbol():
     assert dll.glf_bn_workspace(50176, 2048) == 3 * 1024 * 2048 + 2 * 2048
 
 
+def test_diagnostic_library_is_separate_and_exports_its_header():
+    """include/glfusion_diag.h -> lib/libglfusion_diag.so: the measurement aids of bench.py live outside the product library."""
+    root = os.path.dirname(os.path.dirname(_lib.HEADER))
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "glfusion_diag.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(glf_[a-z0-9_]+)\s*\(", text))
+    assert declared == {"glf_probe_mfma_f16"}
+    diag = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libglfusion_diag.so"))
+    product = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(diag, name) and not hasattr(product, name), name
+    # the workspace queries of the single-call fusion block are host-only
+    tp = _lib.TpaviParams(64, 2352, 2048, 1024, 1, 1e-5, 0.1, 1e-5)
+    product.glf_s16_tpavi_workspace_bytes.restype = ctypes.c_size_t
+    product.glf_s16_tpavi_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    fwd, bwd = (product.glf_s16_tpavi_workspace_bytes(ctypes.byref(tp), k) for k in (0, 1))
+    rows = 64 * 2352
+    assert fwd == 2 * 2048 * 8 and bwd > rows * (2048 + 1024 + 3072) * 2
+    bad = _lib.TpaviParams(0, 2352, 2048, 1024, 1, 1e-5, 0.1, 1e-5)
+    assert product.glf_s16_tpavi_workspace_bytes(ctypes.byref(bad), 1) == 0
+
+
 def test_gemm_params_struct_matches_header_layout():
     # field order / count of the ctypes mirror against the header text
     text = open(_lib.HEADER).read()
