@@ -29,6 +29,28 @@ from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry
 
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
+# Exact-fp32 precision only: the block's NT / NN contractions run as K / EXACT_KCHUNK launches that accumulate into C.  The fp32 MFMA
+# adds its K products ONE AFTER THE OTHER into the accumulator -- a 2 048-long fp32 chain -- and the theta / phi / g weight gradients of
+# a fusion block cancel to ~1e-3 of their terms, so those chains' rounding reaches the gradients at 2-4e-3 (the split-fp16 kernels add
+# 16 products per instruction and sit at 5e-4).  256-deep chains + 8 fp32 adds of the partial results: ~3x less rounding, for one
+# extra read-modify-write of C per chunk -- on the strict-precision leg only.
+EXACT_KCHUNK = int(os.environ.get("GLF_EXACT_KCHUNK", "256"))
+_gemm = gemm
+
+
+def gemm(mode, A, B, Cm, **kw):          # noqa: F811  (every contraction of this module goes through here)
+    K = kw["K"]
+    if split_mode() or mode == "tn" or EXACT_KCHUNK <= 0 or K <= EXACT_KCHUNK or kw.get("taps", 1) != 1:
+        return _gemm(mode, A, B, Cm, **kw)
+    first = True
+    for k0 in range(0, K, EXACT_KCHUNK):
+        kk = dict(kw)
+        kk["K"] = min(EXACT_KCHUNK, K - k0)
+        if not first:
+            kk["bias"] = None
+            kk["accumulate"] = True
+        _gemm(mode, A[..., k0:], B[..., k0:] if mode == "nt" else B[..., k0:, :], Cm, **kk)
+        first = False
 # 'embedded' under the split 16-bit contraction precisions: scores per group of frames through the split-fp16 MFMA kernels (QK^T, PV,
 # dP, dS^T theta, dS phi, P^T dY as plain contractions, softmax statistics in fp32, at most CHUNK_BYTES of scores alive) instead of
 # the fused exact-fp32 kernel -- 3-4x its rate at the model's shapes; 0 = the fused kernel under every precision

@@ -554,9 +554,15 @@ def test_s16_config5_full_clip_T32_on_one_gpu():
     (frames are independent under running statistics: the bf16 fusion features match bit for bit, the fp32 logits -- the 5-channel
     output conv runs on the exact-fp32 kernels, whose tiling depends on the row count -- to 1e-5) and the SUM loss adds up; (b) the train step is finite and every live parameter gets a finite, non-zero-norm gradient; (c) the step's peak
     allocation stays under 130 GB (fp32 storage: 230 GB with retained operand images, 183 GB without)."""
+    import gc
     from glfusion_amd import ops
     from glfusion_amd.models import Global_and_Local
     views, T = ["1", "2", "3", "4", "5"], 32
+    # what earlier tests of the same process still hold (models kept alive by reference cycles, retained operand images, pools) is not
+    # this step's footprint: the peak is taken relative to the allocation level at the start of the test
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
     model = Global_and_Local(views)
     orc.closed_form_fill(model, salt=4)
     model = model.to(DEV)
@@ -592,8 +598,9 @@ def test_s16_config5_full_clip_T32_on_one_gpu():
             if p.grad is not None:
                 assert bool(torch.isfinite(p.grad).all()), n
         assert float(model.layer4["3"][2].conv3.weight.grad.abs().sum()) > 0 and float(model.global_attn.theta.weight.grad.abs().sum()) > 0
-        peak = torch.cuda.max_memory_allocated() / 2 ** 30
-        print(f"s16 config 5, one clip (5 views x 32 x 224^2) on one GPU: loss {lv:.1f}, peak allocation {peak:.0f} GB")
+        peak = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
+        print(f"s16 config 5, one clip (5 views x 32 x 224^2) on one GPU: loss {lv:.1f}, peak allocation {peak:.0f} GB "
+              f"(+ {base / 2 ** 30:.0f} GB held by earlier tests of this process)")
         assert peak < 130
     finally:
         del model, imgs, tgts
