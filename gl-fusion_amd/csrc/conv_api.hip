@@ -182,6 +182,18 @@ extern "C" int glf_conv2d_fwd(const float* x, const float* w_tap, const float* b
     if (pl.plain) { g.n_img = 1; g.hs = g.ws = g.hd = g.wd = 1; g.kh = g.kw = 1; g.stride = 1; g.pad = 0; g.dil = 1; }
     g.batch = 1; g.alpha = 1.f; g.split = 1; g.rect = pl.rect;
     g.amax_a = p->amax_x; g.amax_b = p->amax_w; g.amax_c = p->amax_out; g.colstats = p->colstats; g.precision = p->precision;
+    if (pl.rect == 1 && effective_precision(p) == 0) {
+        // exact fp32: the rectangles one tap per launch.  In one launch the taps of an output pixel meet in float atomics in whatever
+        // order the workgroups finish; launched tap after tap every element receives its (at most nine) addends in tap order -- the
+        // forward pass of the strict-precision leg is reproducible, with the rectangles' short (K-long) fp32 chains kept.  (The
+        // order-dependent last bits were harmless in the forward pass and came back from the model's backward pass as 2-8e-3
+        // run-to-run changes of whole gradient tensors: ops.Conv2dFn.forward, profiles/r04_exact_leg_spread.txt.)
+        for (unsigned mm = pl.tap_mask; mm; mm &= mm - 1) {
+            g.tap_mask = mm & (~mm + 1u);
+            if (int rc = glf_gemm_nt(x, w_tap, bias, y, &g, s)) return rc;
+        }
+        return GLF_OK;
+    }
     return glf_gemm_nt(x, w_tap, bias, y, &g, s);
 }
 

@@ -30,10 +30,12 @@ from .ops import (_chk, _contig, _p, _stream, _tn_split, _ws, _wimage, _registry
 
 FUSED_SOFTMAX = os.environ.get("GLF_FUSED_SOFTMAX", "1") != "0"
 # Exact-fp32 precision only: the block's NT / NN contractions run as K / EXACT_KCHUNK launches that accumulate into C.  The fp32 MFMA
-# adds its K products ONE AFTER THE OTHER into the accumulator -- a 2 048-long fp32 chain -- and the theta / phi / g weight gradients of
-# a fusion block cancel to ~1e-3 of their terms, so those chains' rounding reaches the gradients at 2-4e-3 (the split-fp16 kernels add
-# 16 products per instruction and sit at 5e-4).  256-deep chains + 8 fp32 adds of the partial results: ~3x less rounding, for one
-# extra read-modify-write of C per chunk -- on the strict-precision leg only.
+# adds its K products ONE AFTER THE OTHER into the accumulator -- up to a 3 072-long fp32 chain (dx = du + dqkv Wcat) -- and this
+# block's gradients cancel to ~1e-3 of their terms: unchunked, theta.weight sat at 4.5e-3 of its norm and the encoder gradients
+# behind the block at 2e-3 (the split-fp16 kernels add 16 products per instruction: 5e-4).  Which roundings such a tensor collects is
+# a matter of luck at any single chain length (1 024: 1.0e-3 with a dense ASPP forward, 3.6e-3 with per-tap launches; 512: 2.2e-3);
+# 256-deep chains were within 1e-3 in every regime measured (5.6e-4 / 9.5e-4), for +14 % on the strict-precision leg
+# (profiles/r04_exact_leg_spread.txt -- measurable since the leg is reproducible, see ops.Conv2dFn.forward).
 EXACT_KCHUNK = int(os.environ.get("GLF_EXACT_KCHUNK", "256"))
 _gemm = gemm
 

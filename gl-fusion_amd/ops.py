@@ -929,9 +929,17 @@ class Conv2dFn(Function):
         ok_x = ok and (cout * bin(mask).count("1") >= PRESPLIT_MIN_COLS or packed_hit(x, am_x) is not None)
         xa, pa = (x, True) if x_pk else pick(x, act_packed(x, am_x) if ok_x else None, ok_x)
         wb, pb = pick(wt, weight_packed(wt, weight, "w", am_w) if ok else None, ok)
-        gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
-             taps=taps, mask=mask, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
-             amax_a=am_x, amax_b=am_w, colstats=colstats, colmax=getattr(colstats, "_glf_colmax", None), a_packed=pa, b_packed=pb)
+        # exact fp32 (the strict-precision leg): per-tap rectangles ONE TAP PER LAUNCH.  In one launch the taps of an output pixel meet in
+        # float atomics in whatever order the workgroups finish; the order-dependent last bits of the ASPP outputs are harmless in the
+        # forward pass (loss to 3e-8) and came back from this model's backward pass (BatchNorm over the N per-frame averages of the
+        # pooled branch) as 2-8e-3 run-to-run changes of whole gradient tensors (profiles/r04_exact_leg_spread.txt).  Tap after tap every
+        # element gets its addends in tap order: reproducible, and the rectangles' short fp32 chains are kept (a dense evaluation is a
+        # 9 K-long chain and moved the train-mode logits past 1e-4).
+        masks = [1 << t_ for t_ in range(taps) if (mask >> t_) & 1] if (rect and _PREC[0] == 0) else [mask]
+        for mk in masks:
+            gemm("nt", xa, wb, y, M=n * ho * wo, N=cout, K=cin, lda=cin, ldb=cin, ldc=cout, bias=bias,
+                 taps=taps, mask=mk, tap_stride_b=cout * cin, gather=0 if plain else 1, geo=None if plain else geo, rect=rect,
+                 amax_a=am_x, amax_b=am_w, colstats=colstats, colmax=getattr(colstats, "_glf_colmax", None), a_packed=pa, b_packed=pb)
         ctx.save_for_backward(x, wt)
         ctx.x_packed = (xa, am_x) if (pa and (x_pk or packed_hit(x, am_x) is not None)) else None      # retained: the weight gradient reads the same image
         ctx.join = getattr(x, "_glf_join", None) if plain else None
