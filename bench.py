@@ -318,6 +318,13 @@ def main():
         it shared the chip with other streams' kernels)."""
         ops.set_precision(precision)
         ops.reset_weight_images()                  # the previous leg's weight images are not this leg's per-update work
+        if precision != args.precision:
+            # a secondary leg starts from an empty allocator cache, like the first leg of a fresh process: the blocks the previous
+            # leg left cached have other sizes (the exact leg's split-K slabs are GBs), and a leg that has to hand them back to the
+            # driver in the middle of its timed steps stalls on the synchronising frees (seen once: 1 042 ms per step on the fp16
+            # leg between two runs at 189) -- the W warm-up steps pay for the re-allocation instead
+            gc.collect()
+            torch.cuda.empty_cache()
         if os.environ.get("GLF_BENCH_STEPTIMES", "0") != "0":       # diagnostic: every step fenced and timed (allocator / cache warm-up effects)
             for i in range(args.warmup + args.steps):
                 ts = time.perf_counter()
