@@ -588,7 +588,9 @@ def main():
         torch.cuda.empty_cache()
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--clips", str(args.clips), "--precision", args.precision,
                "--no-exact-f32", "--no-config3", "--no-bf16", "--no-cpu-baseline", "--no-other-mode"] + ([] if use_graph else ["--graph"])
-        env = {k: v for k, v in os.environ.items() if k not in ("GLF_BENCH_GRAPH", "GLF_BENCH_DUMP", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        # (the child must not inherit a profiler's preload: under rocprofv3 it would write into the parent's output directory)
+        env = {k: v for k, v in os.environ.items() if k not in ("GLF_BENCH_GRAPH", "GLF_BENCH_DUMP", "RANK", "WORLD_SIZE", "LOCAL_RANK")
+               and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER")) and not (k == "LD_PRELOAD" and "rocprof" in v.lower())}
         try:
             child = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             if child.returncode == 0:

@@ -2,7 +2,7 @@
 export PYTHONUNBUFFERED=1
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 400 python bench.py --steps 10 --warmup 3 --no-config3 --no-exact-f32 --no-cpu-baseline > gpurun_out/bench_main.json 2> gpurun_out/bench_main.err || { tail -5 gpurun_out/bench_main.err; exit 1; }
+timeout -k 10 400 python bench.py --steps 10 --warmup 3 --no-config3 --no-exact-f32 --no-cpu-baseline --no-other-mode > gpurun_out/bench_main.json 2> gpurun_out/bench_main.err || { tail -5 gpurun_out/bench_main.err; exit 1; }
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench_main.json"))
@@ -11,7 +11,7 @@ print("ms/step", d["ms_per_step"], "eager", d.get("eager_ms_per_step"), "host", 
       "frac", r["frac"], "all", r["all_contractions"]["mfma_frac_of_peak"], "contr s/step", r["all_contractions"]["s_per_step"], "mem", d["peak_mem_gb"])
 PY
 cd /tmp && export TMPDIR=/tmp
-GLF_STREAMS=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python3 $R/bench.py --no-graph --steps 4 --warmup 2 --no-config3 --no-cpu-baseline --no-exact-f32 > /tmp/prof.log 2>&1 || { tail -5 /tmp/prof.log; exit 1; }
+GLF_STREAMS=0 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python3 $R/bench.py --no-graph --steps 4 --warmup 2 --no-config3 --no-cpu-baseline --no-other-mode --no-exact-f32 > /tmp/prof.log 2>&1 || { tail -5 /tmp/prof.log; exit 1; }
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 cp $f $R/gpurun_out/one_stream_kernel_stats.csv
 python3 $R/profiles/ubench/kstats_groups.py $R/gpurun_out/one_stream_kernel_stats.csv 7
