@@ -28,6 +28,8 @@ DT_F32, DT_BF16 = 0, 1
 BLOCK_CALLS = os.environ.get("GLF_BLOCK_CALLS", "1") != "0"
 # gathered weight gradients whose taps fall mostly into the padding reduce over per-tap rectangles (glf_s16_gemm_tn rect = 1); 0 = banded K-tile skipping only
 RECT_WGRAD = os.environ.get("GLF_S16_RECT_WGRAD", "1") != "0"
+# a conv's weight gradient on a side stream of its dgrad (experiment switch; joined before the node returns)
+WGRAD_STREAM16 = os.environ.get("GLF_S16_WGRAD_STREAM", "0") != "0"
 
 
 def _chk16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
@@ -219,17 +221,19 @@ class Conv2d16Fn(Function):
         taps = kh * kw
         rows_o = n * ho * wo
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+
+        def dgrad():
             mask = 1 if plain else _o.tap_mask(2, h, w, ho, wo, kh, kw, stride, pad, dil)
             if mask == 0:
-                dx = _o.zeros(x.shape, dtype=BF, device=x.device)
-            else:
-                rect = 0 if plain else _region(taps, kh, stride, pad, dil, h, w, ho, wo, mask, 2)
-                dx = torch.empty_like(x)
-                wT = weight16(_o.tap_major_T(weight), weight, "wT")
-                gemm16("nt", dy, wT, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin, taps=taps, mask=mask,
-                       tap_stride_b=cout * cin, gather=0 if plain else 2, geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
-        if ctx.needs_input_grad[1]:
+                return _o.zeros(x.shape, dtype=BF, device=x.device)
+            rect = 0 if plain else _region(taps, kh, stride, pad, dil, h, w, ho, wo, mask, 2)
+            dx = torch.empty_like(x)
+            wT = weight16(_o.tap_major_T(weight), weight, "wT")
+            gemm16("nt", dy, wT, dx, M=n * h * w, N=cin, K=cout, lda=cout, ldb=cout, ldc=cin, taps=taps, mask=mask,
+                   tap_stride_b=cout * cin, gather=0 if plain else 2, geo=None if plain else (n, ho, wo, h, w, kh, kw, stride, pad, dil), rect=rect)
+            return dx
+
+        def wgrad():
             mask = 1 if plain else _o.tap_mask(1, ho, wo, h, w, kh, kw, stride, pad, dil)
             ntap = bin(mask).count("1")
             split = tn_split16(rows_o, cout, cin, ntap)
@@ -251,10 +255,30 @@ class Conv2d16Fn(Function):
             gemm16("tn", dy, x, dwt, M=cout, N=cin, K=rows_o, lda=cout, ldb=cin, ldc=cin, taps=taps, mask=mask, tap_stride_b=cout * cin,
                    gather=0 if plain else 1, geo=None if plain else (n, h, w, ho, wo, kh, kw, stride, pad, dil), split=split, rect=rect)
             if taps == 1:
-                dw = dwt.view(wshape)
-            else:
-                dw = _o.grad_out(weight, wshape, x.device)
-                check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+                return dwt.view(wshape)
+            dw = _o.grad_out(weight, wshape, x.device)
+            check(lib.glf_tap_major_to_oihw(_p(dwt), _p(dw), cout, cin, taps, _stream()), "tap_major_to_oihw")
+            return dw
+
+        if WGRAD_STREAM16 and _o.STREAMS and _o.PROFILER is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] \
+                and not torch.cuda.is_current_stream_capturing():
+            # dgrad and wgrad of one conv are independent and read the same dy: the weight gradient goes to a side stream of the
+            # stream this node runs on and is joined before the node returns (ops.Conv2dFn.backward's form)
+            cur = torch.cuda.current_stream()
+            side = _o._wgrad_streams.get(cur.cuda_stream)
+            if side is None:
+                side = _o._wgrad_streams[cur.cuda_stream] = torch.cuda.Stream(device=dy.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dw = wgrad()
+            dx = dgrad()
+            cur.wait_stream(side)
+            dw.record_stream(cur)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = dgrad()
+            if ctx.needs_input_grad[1]:
+                dw = wgrad()
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum16(dy, rows_o, cout)
         return dx, dw, db, None, None, None, None
