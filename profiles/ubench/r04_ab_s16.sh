@@ -5,8 +5,6 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('$2', d['ms_per_step'])"; }
 b bf16 "bf16 default"
-GLF_S16_RED_TPR=32 b bf16 "bf16 red_tpr=32"
-GLF_S16_RED_TPR=64 b bf16 "bf16 red_tpr=64"
-GLF_S16_RED_TPR=128 b bf16 "bf16 red_tpr=128"
+GLF_S16_WGRAD_STREAM=1 b bf16 "bf16 wgrad side stream"
 b bf16 "bf16 default"
-GLF_S16_RED_TPR=32 b bf16 "bf16 red_tpr=32"
+GLF_S16_WGRAD_STREAM=1 b bf16 "bf16 wgrad side stream"
