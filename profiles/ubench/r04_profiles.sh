@@ -37,7 +37,7 @@ if has shapes; then
 fi
 
 if has pmc; then
-  for prec in f16x3 bf16; do
+  for prec in ${PMC_PRECS:-f16x3 bf16}; do
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${prec}_$c -o p --output-format csv -- python3 $R/bench.py --precision $prec --steps 2 --warmup 1 $COMMON > /tmp/pmc_${prec}_$c.log 2>&1 || { tail -3 /tmp/pmc_${prec}_$c.log; exit 1; }
     done
